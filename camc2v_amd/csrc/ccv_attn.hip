@@ -1,0 +1,288 @@
+// ccv_attn_fwd: fused attention forward for head dim 64 on bf16 MFMA (gfx950).
+//
+// One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+// K/V are walked in 64-key tiles staged global -> registers -> LDS (shared by the 4 waves).
+// Per tile and wave:
+//   S^T[key][query] = K . Q^T        v_mfma_f32_32x32x16_bf16, K rows as A, Q rows as B
+//                                     => a lane holds one query column: the softmax row
+//                                        reduction is in-lane + one exchange with lane^32
+//   online softmax in fp32 (base 2), optional bit mask / key bound
+//   O^T[d][query] += V^T . P^T       the S^T accumulator, converted to bf16 in place, IS the
+//                                     B operand (no LDS round trip); V^T fragments come from
+//                                     the row-major V tile through ds_read_b64_tr_b16
+// Masked (epipolar) attention skips whole 128x64 tiles via caller-provided tile flags and,
+// per wave, 32x32 blocks whose mask words are all zero (both exact).  Register tokens are a
+// leading, always-visible K/V segment.  An optional second context (image tokens) is a second
+// softmax pass over the same Q tile, added with a gate.
+#include "ccv_common.h"
+
+namespace {
+
+constexpr int KT = 64;          // keys per tile
+constexpr int K_ROW = 128;      // bytes per K row in LDS (64 bf16), XOR swizzled
+constexpr int V_ROW = 192;      // bytes per V row in LDS (128 + 64 pad: tr reads conflict free)
+constexpr int VT_ROW = 144;     // bytes per V^T row in LDS (variant 1)
+constexpr float NEG_INF = -__builtin_inff();
+
+struct Seg {            // one key/value segment of a softmax pass
+    const uint16_t* k;
+    const uint16_t* v;
+    long k_ls, v_ls;
+    int len;
+    int masked;         // uses mask_bits / tile_flags
+};
+
+template <bool TR>
+__global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[KT * K_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[KT * V_ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, qblk = blockIdx.x;
+    const long bo = b / p.inner, bi = b % p.inner;
+    const int q0 = qblk * 128 + wave * 32;
+    const bool wave_active = q0 < p.Lq;   // wave-uniform
+    const int qi = min(q0 + r, p.Lq - 1); // clamped query index of this lane
+
+    // ---- Q fragments (B operand of S^T): Q[qi][16 s + 8 hh + j] --------------------------
+    bf16x8 qf[4];
+    {
+        const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)qi * p.q_ls + head * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    const float sl2 = p.scale * 1.4426950408889634f;  // softmax in base 2
+
+    f32x16 ofin[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ofin[d][i] = 0.f;
+
+    // Flattened tile schedule: [register tokens][main K/V tiles][second-context tiles].
+    // The second context is its own softmax pass: crossing into it finalises pass 0.
+    const int n_reg = (p.kreg != nullptr && p.nreg > 0) ? 1 : 0;
+    const int n_main = (p.Lk + KT - 1) / KT;
+    const int n_two = (p.k2 != nullptr) ? (p.Lk2 + KT - 1) / KT : 0;
+    const int n_total = n_reg + n_main + n_two;
+    const uint8_t* flags = (p.mask_bits && p.tile_flags) ? p.tile_flags + (long)(b % p.mask_nb) * p.flags_bs + (long)qblk * p.flags_ktiles : nullptr;
+
+    float m_run = NEG_INF, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+
+    {
+        {
+            for (int it = 0; it < n_total; ++it) {
+                if (it == n_reg + n_main) {
+                    // ---- end of pass 0: normalise into the final accumulator, restart the softmax
+                    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+                    const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { ofin[d][i] = oacc[d][i] * wgt; oacc[d][i] = 0.f; }
+                    m_run = NEG_INF;
+                    l_run = 0.f;
+                }
+                Seg seg;
+                int kt;
+                if (it < n_reg) {
+                    seg = Seg{p.kreg + head * 64, p.vreg + head * 64, (long)p.H * 64, (long)p.H * 64, p.nreg, 0};
+                    kt = 0;
+                } else if (it < n_reg + n_main) {
+                    seg = Seg{p.k + bo * p.k_bso + bi * p.k_bsi + head * 64, p.v + bo * p.v_bso + bi * p.v_bsi + head * 64,
+                              (long)p.k_ls, (long)p.v_ls, p.Lk, p.mask_bits != nullptr};
+                    kt = it - n_reg;
+                    if (flags && flags[kt] == 0) continue;  // block-uniform: nothing visible in this tile
+                } else {
+                    seg = Seg{p.k2 + bo * p.k2_bso + bi * p.k2_bsi + head * 64, p.v2 + bo * p.v2_bso + bi * p.v2_bsi + head * 64,
+                              (long)p.k2_ls, (long)p.v2_ls, p.Lk2, 0};
+                    kt = it - n_reg - n_main;
+                }
+                const int k0 = kt * KT;
+                const int nvalid = min(KT, seg.len - k0);
+
+                // ---- stage K and V tiles (zero fill past the end: 0 * garbage must stay 0) ----
+                __syncthreads();  // previous tile fully consumed
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = tid + 256 * i;
+                    const int key = idx >> 3, c = idx & 7;
+                    uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = make_uint4(0u, 0u, 0u, 0u);
+                    if (key < nvalid) {
+                        kv = *reinterpret_cast<const uint4*>(seg.k + (long)(k0 + key) * seg.k_ls + c * 8);
+                        vv = *reinterpret_cast<const uint4*>(seg.v + (long)(k0 + key) * seg.v_ls + c * 8);
+                    }
+                    *reinterpret_cast<uint4*>(sK + key * K_ROW + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
+                    if (TR) {
+                        *reinterpret_cast<uint4*>(sV + key * V_ROW + (c << 4)) = vv;
+                    } else {
+                        const uint16_t* e = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            *reinterpret_cast<uint16_t*>(sV + (8 * c + j) * VT_ROW + key * 2) = e[j];
+                    }
+                }
+                __syncthreads();
+                if (!wave_active) continue;  // wave-uniform; barriers above are still reached next iteration
+
+                // ---- which 32-key blocks does this wave need? --------------------------------
+                uint32_t mw[2] = {0xffffffffu, 0xffffffffu};
+                if (seg.masked) {
+                    const uint32_t* mrow = p.mask_bits + (long)(b % p.mask_nb) * p.mask_bs + (long)qi * p.mask_words;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const int w = (k0 >> 5) + kb;
+                        mw[kb] = (w < p.mask_words) ? mrow[w] : 0u;
+                    }
+                }
+                bool on[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    on[kb] = (32 * kb < nvalid) && (__ballot(mw[kb] != 0u) != 0ull);
+                if (!on[0] && !on[1]) continue;
+
+                // ---- S^T = K Q^T ------------------------------------------------------------
+                f32x16 sacc[2];
+                float tmax = NEG_INF;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+                    if (!on[kb]) continue;
+                    const int krow = 32 * kb + r;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = 2 * s + hh;
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * K_ROW + ((c ^ ((krow >> 1) & 7)) << 4));
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ko = (i & 3) + 8 * (i >> 2) + 4 * hh;  // key offset inside the 32 block
+                        const bool vis = (32 * kb + ko < nvalid) && ((mw[kb] >> ko) & 1u);
+                        const float sv = vis ? sacc[kb][i] * sl2 : NEG_INF;
+                        sacc[kb][i] = sv;
+                        tmax = fmaxf(tmax, sv);
+                    }
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+                m_run = m_new;
+                float psum = 0.f;
+                bf16x8 pf[2][2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (!on[kb]) continue;
+                    float pv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        pv[i] = __builtin_amdgcn_exp2f(sacc[kb][i] - m_use);
+                        psum += pv[i];
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (__bf16)pv[8 * s2 + j];
+                }
+                l_run = l_run * alpha + psum;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+
+                // ---- O^T += V^T P^T -----------------------------------------------------------
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (!on[kb]) continue;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int kb0 = 32 * kb + 16 * s2 + 4 * hh;  // keys kb0..kb0+3 and kb0+8..kb0+11
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            bf16x8 vf;
+                            if (TR) {
+                                const int li = lane & 15, g = (lane >> 4) & 1;
+                                const int dcol = 32 * d + 16 * g + 4 * (li & 3);
+                                const unsigned char* a0 = sV + (kb0 + (li >> 2)) * V_ROW + dcol * 2;
+                                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                    (__attribute__((address_space(3))) bf16x4*)(a0));
+                                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                    (__attribute__((address_space(3))) bf16x4*)(a0 + 8 * V_ROW));
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                            } else {
+                                const unsigned char* a0 = sV + (32 * d + r) * VT_ROW + kb0 * 2;
+                                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(a0);
+                                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(a0 + 16);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                            }
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[d], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- finish the last pass -------------------------------------------------------------
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float wgt = (l_tot > 0.f ? 1.0f / l_tot : 0.f) * (n_two > 0 ? p.gate2 : 1.0f);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ofin[d][i] += oacc[d][i] * wgt;
+    }
+
+    // ---- store O[query][head*64 + d]: lane holds column `query`, rows d ------------------
+    if (wave_active && q0 + r < p.Lq) {
+        uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)(q0 + r) * p.o_ls + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = 32 * d + 8 * g4 + 4 * hh;
+                uint2 pk = make_uint2(pack_bf16x2(ofin[d][4 * g4], ofin[d][4 * g4 + 1]),
+                                      pack_bf16x2(ofin[d][4 * g4 + 2], ofin[d][4 * g4 + 3]));
+                *reinterpret_cast<uint2*>(op + dd) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
+    CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_attn_fwd: null params");
+    const CcvAttn& p = *pp;
+    CCV_REQUIRE(p.q && p.k && p.v && p.o, CCV_EINVAL, "ccv_attn_fwd: null q/k/v/o");
+    CCV_REQUIRE(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0 && p.inner > 0, CCV_EINVAL,
+                "ccv_attn_fwd: non-positive B/H/Lq/Lk/inner (%d,%d,%d,%d,%d)", p.B, p.H, p.Lq, p.Lk, p.inner);
+    CCV_REQUIRE(p.H <= 65535, CCV_ESHAPE, "ccv_attn_fwd: too many heads");
+    CCV_REQUIRE((p.q_ls % 8 == 0) && (p.k_ls % 8 == 0) && (p.v_ls % 8 == 0) && (p.o_ls % 4 == 0), CCV_ESHAPE,
+                "ccv_attn_fwd: token strides must keep 16-byte alignment");
+    CCV_REQUIRE(!p.k2 || (p.v2 && p.Lk2 > 0), CCV_EINVAL, "ccv_attn_fwd: second context needs k2, v2, Lk2");
+    CCV_REQUIRE(!p.mask_bits || p.mask_words * 32 >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: mask_words too small");
+    CCV_REQUIRE(!p.mask_bits || p.mask_nb > 0, CCV_EINVAL, "ccv_attn_fwd: mask_nb must be positive");
+    CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
+    CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
+    CCV_REQUIRE(p.nreg <= KT, CCV_ESHAPE, "ccv_attn_fwd: at most 64 register tokens");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // gridDim.z is limited to 65535: fold large batches (temporal attention: one batch per pixel)
+    CCV_REQUIRE(p.B <= 65535, CCV_ESHAPE, "ccv_attn_fwd: B=%d exceeds 65535 (split the call)", p.B);
+    dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+    if (p.variant == 0)
+        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, p);
+    CCV_LAUNCH_CHECK("ccv_attn_fwd");
+    return CCV_OK;
+}

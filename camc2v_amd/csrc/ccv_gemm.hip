@@ -1,0 +1,311 @@
+// ccv_gemm: implicit-GEMM (linear / conv3x3 / temporal conv) on bf16 MFMA for gfx950.
+//
+// C[M,N] = epilogue( sum_tap gather_tap(A)[M,K] . W_tap[N,K]^T ),  fp32 accumulate.
+//
+// Tiling: one workgroup = 256 threads = 4 waves (2 x 2), block tile (32*MT) x (32*NT),
+// wave tile (16*MT) x (16*NT) built from v_mfma_f32_16x16x32_bf16.  The MFMA is issued
+// with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B operand,
+// so a lane ends up with 4 consecutive output columns of one output row: bias, residual
+// and the store are 8/16-byte vector accesses and GEGLU pairs live in one lane.
+// K is walked in 64-wide slabs; both operands are staged global -> registers -> LDS
+// (register staging lets the loader zero-fill conv padding, convert fp32 activations and
+// gather rows per tap), LDS is double buffered and XOR-swizzled so the ds_read_b128
+// fragment reads are bank-conflict free (16-byte chunk c of row r lives at c ^ ((r>>1)&7)).
+// blockIdx is remapped so that the workgroups of one XCD walk neighbouring tiles (L2 reuse).
+#include "ccv_common.h"
+
+namespace {
+
+constexpr int BK = 64;  // bf16 elements per K slab = 128 bytes per LDS row
+
+template <int MT, int NT, bool A_F32, int GATHER>
+__global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                 // [2][BM][128 B]
+    unsigned char* sB = smem + 2 * BM * 128;  // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile assignment (bijective for any grid size) ----------------------
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    // ---- per-thread staging geometry ----------------------------------------------------
+    const int chunk = tid & 7;   // 16-byte chunk (8 bf16) within the 64-wide slab
+    const int srow = tid >> 3;   // 0..31
+    int a_base[AR], a_y[AR], a_x[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + srow + 32 * i;
+        if (GATHER == 0) {
+            a_base[i] = (m < p.M) ? m : -1;
+            a_y[i] = a_x[i] = 0;
+        } else if (GATHER == 1) {
+            const int pix = p.out_h * p.out_w;
+            const int img = m / pix, rem = m - img * pix;
+            const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+            a_base[i] = (m < p.M) ? img * p.src_h * p.src_w : -1;
+            a_y[i] = oy * p.stride - 1;
+            a_x[i] = ox * p.stride - 1;
+        } else {
+            a_base[i] = (m < p.M) ? m : -1;
+            a_y[i] = (m / p.hw) % p.frames;  // frame index within the clip
+            a_x[i] = 0;
+        }
+    }
+    const int slabs_per_tap = p.K / BK;
+    const int nslab = p.taps * slabs_per_tap;
+    const int ldw = p.taps * p.K;
+
+    uint4 ra[AR];            // bf16 path
+    float4 rf[A_F32 ? 2 * AR : 1];  // fp32 path (converted when written to LDS)
+    uint4 rb[BR];
+
+    auto load_slab = [&](int s) {
+        const int tap = s / slabs_per_tap;
+        const int kc = (s - tap * slabs_per_tap) * BK + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            long src = -1;
+            if (a_base[i] >= 0) {
+                if (GATHER == 0) {
+                    src = a_base[i];
+                } else if (GATHER == 1) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+                    const int vh = p.src_h << p.upsample, vw = p.src_w << p.upsample;
+                    if (iy >= 0 && iy < vh && ix >= 0 && ix < vw)
+                        src = a_base[i] + (iy >> p.upsample) * p.src_w + (ix >> p.upsample);
+                } else {
+                    const int f = a_y[i] + tap - 1;
+                    if (f >= 0 && f < p.frames) src = (long)a_base[i] + (long)(tap - 1) * p.hw;
+                }
+            }
+            if (A_F32) {
+                if (src >= 0) {
+                    const float4* g = reinterpret_cast<const float4*>(static_cast<const float*>(p.A) + src * p.lda + kc);
+                    rf[2 * i] = g[0];
+                    rf[2 * i + 1] = g[1];
+                } else {
+                    rf[2 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rf[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                if (src >= 0)
+                    ra[i] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.A) + src * p.lda + kc);
+                else
+                    ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        const int kw = s * BK + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + srow + 32 * i;
+            if (n < p.N)
+                rb[i] = *reinterpret_cast<const uint4*>(p.W + (long)n * ldw + kw);
+            else
+                rb[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int r = srow + 32 * i;
+            uint4 v;
+            if (A_F32) {
+                const float4 lo = rf[2 * i], hi = rf[2 * i + 1];
+                v.x = pack_bf16x2(lo.x, lo.y);
+                v.y = pack_bf16x2(lo.z, lo.w);
+                v.z = pack_bf16x2(hi.x, hi.y);
+                v.w = pack_bf16x2(hi.z, hi.w);
+            } else {
+                v = ra[i];
+            }
+            *reinterpret_cast<uint4*>(sA + (buf * BM + r) * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<uint4*>(sB + (buf * BN + r) * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15;  // fragment row (m for activations, n for weights)
+    const int fg = lane >> 4;  // k group: 8 consecutive k at 8*fg
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load_slab(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + fg;
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * 16 * MT + 16 * i + fr;
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + (buf * BM + r) * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * 16 * NT + 16 * j + fr;
+                fb[j] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + r) * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    // weights as the MFMA A operand (rows = n), activations as B (cols = m)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = ..+fr, n = ..+4*fg ---------------------
+    const int ldc = p.ldc;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * 16 * MT + 16 * i + fr;
+        if (m >= p.M) continue;
+        const float* b2 = p.bias2 ? p.bias2 + (long)(m / p.rows_per_batch) * p.ldb2 : nullptr;
+        if (p.geglu) {
+#pragma unroll
+            for (int j = 0; j < NT; j += 2) {
+                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;  // value columns; gate at n + 16
+                if (n >= p.N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = acc[i][j][r] * p.alpha, g = acc[i][j + 1][r] * p.alpha;
+                    if (p.bias) { a += p.bias[n + r]; g += p.bias[n + 16 + r]; }
+                    o[r] = a * gelu_erf_f(g);
+                }
+                const int nc = (n0 + wn * 16 * NT + 16 * j) / 2 + 4 * fg;
+                uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * ldc + nc) = pk;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+            if (n >= p.N) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r] * p.alpha;
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            }
+            if (b2) {
+                const float4 bv = *reinterpret_cast<const float4*>(b2 + n);
+                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r]);
+            }
+            if (p.residual) {
+                const float4 rv = *reinterpret_cast<const float4*>(p.residual + (long)m * p.ldr + n);
+                o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+            }
+            if (p.out_f32) {
+                *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * ldc + n) = pk;
+            }
+        }
+    }
+}
+
+template <int MT, int NT, bool A_F32, int GATHER>
+int launch(const CcvGemm& p, hipStream_t st) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const size_t lds = 2 * (BM + BN) * 128;
+    auto kern = gemm_kernel<MT, NT, A_F32, GATHER>;
+    static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm");
+    return CCV_OK;
+}
+
+template <bool A_F32, int GATHER>
+int dispatch_tile(const CcvGemm& p, hipStream_t st) {
+    // Largest tile that still yields >= ~1 workgroup per CU (256 CUs); small problems
+    // take the 64x64 tile so the 4x4-latent layers are not left on a handful of CUs.
+    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if (p.N % 128 == 0 && tiles(128, 128) >= 256) return launch<4, 4, A_F32, GATHER>(p, st);
+    if (p.N % 128 == 0 && tiles(64, 128) >= 256) return launch<2, 4, A_F32, GATHER>(p, st);
+    if (p.N % 64 == 0 && tiles(128, 64) >= 320) return launch<4, 2, A_F32, GATHER>(p, st);
+    return launch<2, 2, A_F32, GATHER>(p, st);
+}
+
+}  // namespace
+
+extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
+    CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_gemm: null params");
+    const CcvGemm& p = *pp;
+    CCV_REQUIRE(p.A && p.W && p.C, CCV_EINVAL, "ccv_gemm: null A/W/C");
+    CCV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, CCV_EINVAL, "ccv_gemm: non-positive M/N/K (%d,%d,%d)", p.M, p.N, p.K);
+    CCV_REQUIRE(p.K % BK == 0, CCV_ESHAPE, "ccv_gemm: K=%d must be a multiple of 64", p.K);
+    CCV_REQUIRE(p.N % 16 == 0, CCV_ESHAPE, "ccv_gemm: N=%d must be a multiple of 16", p.N);
+    CCV_REQUIRE(!p.geglu || (p.N % 32 == 0 && !p.out_f32 && !p.residual && !p.bias2), CCV_ESHAPE,
+                "ccv_gemm: geglu needs N%%32==0, bf16 output, no residual/bias2");
+    CCV_REQUIRE(p.lda % 8 == 0 && p.ldc % 4 == 0 && (!p.residual || p.ldr % 4 == 0), CCV_ESHAPE,
+                "ccv_gemm: leading dimensions must keep 16-byte row alignment (lda=%d ldc=%d ldr=%d)", p.lda, p.ldc, p.ldr);
+    CCV_REQUIRE(p.lda >= p.K, CCV_ESHAPE, "ccv_gemm: lda=%d < K=%d", p.lda, p.K);
+    CCV_REQUIRE(!p.bias2 || (p.rows_per_batch > 0 && p.ldb2 >= p.N && p.ldb2 % 4 == 0), CCV_EINVAL,
+                "ccv_gemm: bias2 needs rows_per_batch > 0 and ldb2 >= N (multiple of 4)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (p.gather) {
+        case 0:
+            CCV_REQUIRE(p.taps == 1, CCV_EINVAL, "ccv_gemm: linear gather needs taps == 1");
+            return p.a_f32 ? dispatch_tile<true, 0>(p, st) : dispatch_tile<false, 0>(p, st);
+        case 1:
+            CCV_REQUIRE(p.taps == 9, CCV_EINVAL, "ccv_gemm: conv3x3 gather needs taps == 9");
+            CCV_REQUIRE(p.out_h > 0 && p.out_w > 0 && p.src_h > 0 && p.src_w > 0 && (p.stride == 1 || p.stride == 2) &&
+                            (p.upsample == 0 || p.upsample == 1) && p.M % (p.out_h * p.out_w) == 0,
+                        CCV_EINVAL, "ccv_gemm: bad conv geometry");
+            return p.a_f32 ? dispatch_tile<true, 1>(p, st) : dispatch_tile<false, 1>(p, st);
+        case 2:
+            CCV_REQUIRE(p.taps == 3, CCV_EINVAL, "ccv_gemm: tconv3 gather needs taps == 3");
+            CCV_REQUIRE(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0, CCV_EINVAL, "ccv_gemm: bad tconv geometry");
+            CCV_REQUIRE(!p.a_f32, CCV_ESHAPE, "ccv_gemm: tconv3 takes bf16 activations");
+            return dispatch_tile<false, 2>(p, st);
+        default:
+            ccv_set_error("ccv_gemm: unknown gather %d", p.gather);
+            return CCV_EINVAL;
+    }
+}

@@ -1,0 +1,98 @@
+"""ctypes binding of libccv_hip.so (the C ABI declared in include/ccv.h).
+
+The product path has no CPU fallback: if the shared library is missing, cannot be
+loaded, or an entry point is absent, importing this module's ``lib()`` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libccv_hip.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class CcvGemm(C.Structure):
+    _fields_ = [
+        ("A", vp), ("W", vp), ("C", vp), ("bias", vp), ("bias2", vp), ("residual", vp),
+        ("M", i32), ("N", i32), ("K", i32), ("taps", i32),
+        ("lda", i32), ("ldc", i32), ("ldr", i32), ("ldb2", i32),
+        ("a_f32", i32), ("gather", i32),
+        ("out_h", i32), ("out_w", i32), ("src_h", i32), ("src_w", i32),
+        ("stride", i32), ("upsample", i32), ("frames", i32), ("hw", i32),
+        ("rows_per_batch", i32), ("act", i32), ("geglu", i32), ("out_f32", i32),
+        ("alpha", f32),
+    ]
+
+
+class CcvAttn(C.Structure):
+    _fields_ = [
+        ("q", vp), ("k", vp), ("v", vp), ("o", vp),
+        ("q_bso", i64), ("q_bsi", i64), ("q_ls", i64),
+        ("k_bso", i64), ("k_bsi", i64), ("k_ls", i64),
+        ("v_bso", i64), ("v_bsi", i64), ("v_ls", i64),
+        ("o_bso", i64), ("o_bsi", i64), ("o_ls", i64),
+        ("B", i32), ("inner", i32), ("H", i32), ("Lq", i32), ("Lk", i32),
+        ("scale", f32),
+        ("k2", vp), ("v2", vp),
+        ("k2_bso", i64), ("k2_bsi", i64), ("k2_ls", i64),
+        ("v2_bso", i64), ("v2_bsi", i64), ("v2_ls", i64),
+        ("Lk2", i32), ("gate2", f32),
+        ("mask_bits", vp), ("mask_bs", i64), ("mask_words", i32), ("mask_nb", i32),
+        ("tile_flags", vp), ("flags_bs", i64), ("flags_ktiles", i32),
+        ("kreg", vp), ("vreg", vp), ("nreg", i32),
+        ("variant", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ccv.h declares
+SIGNATURES = {
+    "ccv_version": (i32, []),
+    "ccv_last_error": (C.c_char_p, []),
+    "ccv_gemm": (i32, [C.POINTER(CcvGemm), vp]),
+    "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
+    "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
+    "ccv_groupnorm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
+    "ccv_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp, vp]),
+    "ccv_pack_nchw_to_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "ccv_unpack_rows_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
+    "ccv_concat_rows": (i32, [vp, i32, vp, i32, vp, i64, vp]),
+    "ccv_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "ccv_nchw_to_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "ccv_timestep_embedding": (i32, [vp, vp, i32, i32, vp]),
+    "ccv_add_silu_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "ccv_ddim_cfg_step": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i64, vp, vp]),
+    "ccv_pack_mask": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "ccv_epipolar_mask_bits": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+}
+
+_lib = None
+
+
+class CcvError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CcvError(
+                f"{LIB_PATH} is missing: build it with `python -m camc2v_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback on the product path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.ccv_version() < 100:
+            raise CcvError("libccv_hip.so is older than this package")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ccv_last_error()
+        raise CcvError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

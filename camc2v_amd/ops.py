@@ -1,0 +1,295 @@
+"""Tensor-level wrappers over the C ABI (include/ccv.h).
+
+torch is used for device memory and streams only: every wrapper checks device /
+dtype / layout, allocates the output with torch.empty and launches the HIP kernel
+on torch's current stream.  There is no CPU path: a CPU tensor raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from .lib import CcvAttn, CcvError, CcvGemm, check, lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+GATHER_LINEAR, GATHER_CONV3X3, GATHER_TCONV3 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+# 0: V^T fragments through ds_read_b64_tr_b16; 1: V transposed while staging (fallback)
+ATTN_VARIANT = 0
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise CcvError("camc2v_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _rows(t):
+    """[..., C] contiguous -> (rows, C)."""
+    if not t.is_contiguous():
+        raise CcvError("expected a contiguous tensor")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+# ---------------------------------------------------------------------------------------
+# GEMM family
+# ---------------------------------------------------------------------------------------
+def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
+         residual=None, act=ACT_NONE, geglu=False, out_f32=False, out=None, gather=GATHER_LINEAR,
+         conv=None, tconv=None, alpha=1.0):
+    """out[m, n] = epilogue(sum_tap gather(a) @ w_tap^T).  See include/ccv.h (ccv_gemm).
+
+    a: [rows, lda] bf16 or fp32 (2-D, last dim contiguous); w: [N, taps*K] bf16.
+    conv = (out_h, out_w, src_h, src_w, stride, upsample); tconv = (frames, hw).
+    """
+    _dev(a, w, bias, bias2, residual, out)
+    if a.dim() != 2 or a.stride(1) != 1:
+        raise CcvError("gemm: A must be 2-D with a contiguous last dim")
+    if w.dtype != BF16 or not w.is_contiguous():
+        raise CcvError("gemm: W must be contiguous bf16")
+    N = w.shape[0]
+    K = k if k is not None else w.shape[1] // taps
+    if w.shape[1] != taps * K:
+        raise CcvError(f"gemm: W has {w.shape[1]} columns, expected taps*K = {taps}*{K}")
+    M = m if m is not None else a.shape[0]
+    n_cols = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_cols), dtype=F32 if out_f32 else BF16, device=a.device)
+    p = CcvGemm()
+    p.A, p.W, p.C = _ptr(a), _ptr(w), _ptr(out)
+    p.bias, p.bias2, p.residual = _ptr(bias), _ptr(bias2), _ptr(residual)
+    p.M, p.N, p.K, p.taps = M, N, K, taps
+    p.lda = lda if lda is not None else a.stride(0)
+    p.ldc = out.stride(0)
+    p.ldr = residual.stride(0) if residual is not None else 0
+    p.ldb2 = ldb2 if bias2 is not None else 0
+    if a.dtype == F32:
+        p.a_f32 = 1
+    elif a.dtype == BF16:
+        p.a_f32 = 0
+    else:
+        raise CcvError(f"gemm: unsupported A dtype {a.dtype}")
+    if bias is not None and (bias.dtype != F32 or bias.numel() < N):
+        raise CcvError("gemm: bias must be fp32 [N]")
+    if residual is not None and residual.dtype != F32:
+        raise CcvError("gemm: residual must be fp32")
+    if out.dtype != (F32 if out_f32 else BF16):
+        raise CcvError("gemm: out dtype mismatch")
+    p.gather = gather
+    if gather == GATHER_CONV3X3:
+        p.out_h, p.out_w, p.src_h, p.src_w, p.stride, p.upsample = conv
+    elif gather == GATHER_TCONV3:
+        p.frames, p.hw = tconv
+    p.rows_per_batch = rows_per_batch
+    p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), int(out_f32), alpha
+    check(lib().ccv_gemm(C.byref(p), _stream()), "ccv_gemm")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------
+def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_str=None, scale=None,
+              k2=None, v2=None, k2_str=None, v2_str=None, Lk2=0, gate2=1.0,
+              mask_bits=None, mask_nb=1, tile_flags=None, kreg=None, vreg=None, variant=None):
+    """Fused attention, head dim 64.  *_str = (batch_outer, batch_inner, token) strides in elements;
+    q/k/v are bf16 tensors whose data_ptr() is the element (batch 0, token 0, head 0, d 0).
+    Returns bf16 [B*Lq, H*64] unless `out`/`o_str` are given."""
+    _dev(q, k, v, k2, v2, mask_bits, tile_flags, kreg, vreg, out)
+    for t in (q, k, v, k2, v2, kreg, vreg):
+        if t is not None and t.dtype != BF16:
+            raise CcvError("attention: q/k/v must be bf16")
+    if out is None:
+        out = torch.empty((B * Lq, H * 64), dtype=BF16, device=q.device)
+        o_str = ((Lq * H * 64) * inner, Lq * H * 64, H * 64)
+    p = CcvAttn()
+    p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(out)
+    p.q_bso, p.q_bsi, p.q_ls = q_str
+    p.k_bso, p.k_bsi, p.k_ls = k_str
+    p.v_bso, p.v_bsi, p.v_ls = v_str
+    p.o_bso, p.o_bsi, p.o_ls = o_str
+    p.B, p.inner, p.H, p.Lq, p.Lk = B, inner, H, Lq, Lk
+    p.scale = scale if scale is not None else 1.0 / math.sqrt(64.0)
+    if k2 is not None:
+        p.k2, p.v2 = _ptr(k2), _ptr(v2)
+        p.k2_bso, p.k2_bsi, p.k2_ls = k2_str
+        p.v2_bso, p.v2_bsi, p.v2_ls = v2_str
+        p.Lk2, p.gate2 = Lk2, gate2
+    if mask_bits is not None:
+        if mask_bits.dtype != torch.int32 or not mask_bits.is_contiguous():
+            raise CcvError("attention: mask_bits must be contiguous int32 [nb, Lq, words]")
+        p.mask_bits = _ptr(mask_bits)
+        p.mask_words = mask_bits.shape[-1]
+        p.mask_bs = mask_bits.shape[-2] * mask_bits.shape[-1]
+        p.mask_nb = mask_nb
+        if tile_flags is not None:
+            p.tile_flags = _ptr(tile_flags)
+            p.flags_ktiles = tile_flags.shape[-1]
+            p.flags_bs = tile_flags.shape[-2] * tile_flags.shape[-1]
+    if kreg is not None:
+        p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
+    p.variant = ATTN_VARIANT if variant is None else variant
+    check(lib().ccv_attn_fwd(C.byref(p), _stream()), "ccv_attn_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------
+def groupnorm(x, gamma, beta, *, instances, eps, silu):
+    """x [rows, C] fp32|bf16 -> bf16; statistics per (instance, group of C/32 channels)."""
+    _dev(x, gamma, beta)
+    rows, Cc = _rows(x)
+    if rows % instances:
+        raise CcvError("groupnorm: rows not divisible by instances")
+    y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    ws = torch.empty(lib().ccv_groupnorm_ws_bytes(instances, Cc), dtype=torch.uint8, device=x.device)
+    check(lib().ccv_groupnorm(_ptr(x), int(x.dtype == F32), _ptr(y), _ptr(gamma), _ptr(beta), instances,
+                              rows // instances, Cc, eps, int(silu), _ptr(ws), _stream()), "ccv_groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, *, eps=1e-5, addend=None):
+    """x [rows, C] fp32 -> bf16 (and y + addend[r % addend_rows] when addend is given)."""
+    _dev(x, gamma, beta, addend)
+    if x.dtype != F32:
+        raise CcvError("layernorm: x must be fp32 (the residual stream)")
+    rows, Cc = _rows(x)
+    y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    y2 = None
+    arows = 0
+    if addend is not None:
+        if addend.dtype != BF16 or not addend.is_contiguous() or addend.shape[-1] != Cc:
+            raise CcvError("layernorm: addend must be contiguous bf16 [rows', C]")
+        arows = addend.numel() // Cc
+        y2 = torch.empty_like(y)
+    check(lib().ccv_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _ptr(addend), arows,
+                              _ptr(y2), _stream()), "ccv_layernorm")
+    return (y, y2) if addend is not None else y
+
+
+# ---------------------------------------------------------------------------------------
+# layout / elementwise
+# ---------------------------------------------------------------------------------------
+def pack_nchw_to_rows(x, x2=None, ldo=64):
+    """cat([x, x2], 1) as token-major fp32 rows [(b t h w), ldo], zero padded."""
+    _dev(x, x2)
+    x = x.contiguous().float()
+    b, c1, t, h, w = x.shape
+    c2 = 0
+    if x2 is not None:
+        x2 = x2.contiguous().float()
+        c2 = x2.shape[1]
+    out = torch.empty((b * t * h * w, ldo), dtype=F32, device=x.device)
+    check(lib().ccv_pack_nchw_to_rows(_ptr(x), c1, _ptr(x2), c2, _ptr(out), ldo, b, t, h * w, _stream()),
+          "ccv_pack_nchw_to_rows")
+    return out
+
+
+def unpack_rows_to_nchw(rows, c, b, t, h, w):
+    _dev(rows)
+    out = torch.empty((b, c, t, h, w), dtype=F32, device=rows.device)
+    check(lib().ccv_unpack_rows_to_nchw(_ptr(rows), rows.stride(0), _ptr(out), c, b, t, h * w, _stream()),
+          "ccv_unpack_rows_to_nchw")
+    return out
+
+
+def concat_rows(a, b):
+    _dev(a, b)
+    rows, ca = _rows(a)
+    rows_b, cb = _rows(b)
+    if rows != rows_b or a.dtype != F32 or b.dtype != F32:
+        raise CcvError("concat_rows: fp32 inputs with equal row counts expected")
+    out = torch.empty((rows, ca + cb), dtype=F32, device=a.device)
+    check(lib().ccv_concat_rows(_ptr(a), ca, _ptr(b), cb, _ptr(out), rows, _stream()), "ccv_concat_rows")
+    return out
+
+
+def cast_bf16(x):
+    _dev(x)
+    x = x.contiguous()
+    if x.dtype != F32:
+        raise CcvError("cast_bf16: fp32 input expected")
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib().ccv_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "ccv_cast_bf16")
+    return y
+
+
+def nchw_to_rows_bf16(x):
+    """[b, c, t, h, w] fp32 -> [(b t h w), c] bf16."""
+    _dev(x)
+    x = x.contiguous().float()
+    b, c, t, h, w = x.shape
+    y = torch.empty((b * t * h * w, c), dtype=BF16, device=x.device)
+    check(lib().ccv_nchw_to_rows_bf16(_ptr(x), _ptr(y), b, c, t, h * w, _stream()), "ccv_nchw_to_rows_bf16")
+    return y
+
+
+def timestep_embedding(t, dim):
+    """t [n] (any numeric dtype) -> [n, dim] bf16, cos | sin."""
+    _dev(t)
+    tf = t.to(F32).contiguous()
+    out = torch.empty((tf.numel(), dim), dtype=BF16, device=t.device)
+    check(lib().ccv_timestep_embedding(_ptr(tf), _ptr(out), tf.numel(), dim, _stream()), "ccv_timestep_embedding")
+    return out
+
+
+def add_silu_bf16(a, b=None):
+    _dev(a, b)
+    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    check(lib().ccv_add_silu_bf16(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "ccv_add_silu_bf16")
+    return out
+
+
+def ddim_cfg_step(x, e_c, e_uc, noise, coef, scale, guidance_rescale, want_x0=True):
+    """Fused CFG + rescale + DDIM update.  coef: device fp32 [4] = (a_t, a_prev, sigma_t, sqrt(1-a_t))."""
+    _dev(x, e_c, e_uc, noise, coef)
+    for t in (x, e_c, e_uc, noise):
+        if t is not None and (t.dtype != F32 or not t.is_contiguous()):
+            raise CcvError("ddim_cfg_step: contiguous fp32 tensors expected")
+    n = x.shape[0]
+    per = x.numel() // n
+    x_prev = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    ws = torch.empty((n, 4), dtype=F32, device=x.device)
+    check(lib().ccv_ddim_cfg_step(_ptr(x), _ptr(e_c), _ptr(e_uc), _ptr(noise), _ptr(x_prev), _ptr(x0), _ptr(coef),
+                                  float(scale), float(guidance_rescale), n, per, _ptr(ws), _stream()),
+          "ccv_ddim_cfg_step")
+    return x_prev, x0
+
+
+def pack_mask(mask):
+    """bool [B, Lq, Lk] -> (bits int32 [B, Lq, ceil(Lk/32)], flags uint8 [B, ceil(Lq/128), ceil(Lk/64)])."""
+    _dev(mask)
+    if mask.dtype != torch.bool or mask.dim() != 3:
+        raise CcvError("pack_mask: bool [B, Lq, Lk] expected")
+    mask = mask.contiguous()
+    B, Lq, Lk = mask.shape
+    bits = torch.empty((B, Lq, (Lk + 31) // 32), dtype=torch.int32, device=mask.device)
+    flags = torch.zeros((B, (Lq + 127) // 128, (Lk + 63) // 64), dtype=torch.uint8, device=mask.device)
+    check(lib().ccv_pack_mask(_ptr(mask), _ptr(bits), _ptr(flags), B, Lq, Lk, _stream()), "ccv_pack_mask")
+    return bits, flags
+
+
+def epipolar_mask_bits(F, T, H, W, downsample):
+    """F [B, T, T, 3, 3] fp32 -> packed epipolar mask (bits, flags) for an HxW feature map."""
+    _dev(F)
+    F = F.contiguous().float()
+    B = F.shape[0]
+    L = T * H * W
+    bits = torch.empty((B, L, (L + 31) // 32), dtype=torch.int32, device=F.device)
+    flags = torch.zeros((B, (L + 127) // 128, (L + 63) // 64), dtype=torch.uint8, device=F.device)
+    check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), B, T, H, W, downsample, _stream()),
+          "ccv_epipolar_mask_bits")
+    return bits, flags

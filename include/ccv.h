@@ -1,0 +1,211 @@
+/* ccv.h -- C ABI of libccv_hip.so, the MI355X (gfx950) kernel library behind the
+ * CamContextI2V DDIM denoising hot path.
+ *
+ * Boundary contract (last row):
+ *   - flat extern "C" functions, plain pointers + sizes, no torch / C++ types;
+ *   - every pointer is a DEVICE pointer unless the name says otherwise; the caller
+ *     allocates every input, output and workspace; the library holds no tensors;
+ *   - every launch is asynchronous on the `stream` argument (a hipStream_t passed as
+ *     void*; NULL = the default stream); nothing synchronises, allocates or copies
+ *     synchronously, so every entry point may be captured into a hipGraph;
+ *   - return value: 0 = ok, negative = argument/shape error (CCV_E*), positive = the
+ *     hipError_t of the failed launch; ccv_last_error() returns a thread-local message;
+ *   - stateless and re-entrant; one process per GPU.
+ *
+ * Each entry point names the reference call site(s) it replaces (paths relative to
+ * /root/reference/CamContextI2V).  The reference has no native code: every function
+ * here stands in for a third-party kernel the reference reaches through torch,
+ * xformers or F.scaled_dot_product_attention.
+ *
+ * Layouts: activations are token-major ("NHWC"): a tensor [b, t, h, w, C] is a row-major
+ * matrix [rows = b*t*h*w, C].  The residual stream is fp32, GEMM/attention operands bf16
+ * (raw uint16 bit patterns), statistics and accumulation fp32.
+ */
+#ifndef CCV_H_
+#define CCV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCV_VERSION 100 /* 0.1.0 */
+
+enum {
+    CCV_OK = 0,
+    CCV_EINVAL = -1,  /* bad argument (null pointer, negative size, unknown enum) */
+    CCV_ESHAPE = -2,  /* shape not supported by the kernel (alignment, head dim) */
+};
+
+int ccv_version(void);
+const char* ccv_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * ccv_gemm: C = epilogue( sum_tap gather_tap(A) @ W_tap^T )      bf16 MFMA, fp32 accumulate
+ *
+ * Replaces: every nn.Linear of the path (lvdm/modules/attention.py:58-62,277,301,348,378,
+ * 434,454; model/modules/epipolar.py:55-63; model/camcontexti2v.py:152), nn.Conv2d 3x3 /
+ * 1x1 of ResBlock, Downsample, Upsample and the UNet in/out convs
+ * (lvdm/modules/networks/openaimodel3d.py:68,96,151-187,386,564), nn.Conv3d (3,1,1) of
+ * TemporalConvBlock (:255-266), the time-embedding add (:219-228), the residual adds
+ * (:230, attention.py:250-252,320,428) and GEGLU (attention.py:431-438).
+ *
+ * A  : [src_rows, lda] bf16 or fp32 (a_f32), row-major.  Row m of the implicit im2col
+ *      matrix is gathered per tap:
+ *        gather 0 (linear)  : source row m, taps = 1
+ *        gather 1 (conv3x3) : m = (img, oy, ox); tap (ky,kx) reads source pixel
+ *                             (oy*stride+ky-1, ox*stride+kx-1) of image img, zero outside;
+ *                             with `upsample` the source image (src_h x src_w) is first
+ *                             nearest-upsampled 2x (F.interpolate, openaimodel3d.py:103)
+ *        gather 2 (tconv3)  : m = (clip, frame, pixel); tap kt reads frame+kt-1, zero outside
+ * W  : [N, taps*K] bf16 row-major, k index = tap*K + c  (prepared once from the checkpoint)
+ * out: v = alpha*acc + bias[n] + bias2[(m / rows_per_batch)*ldb2 + n]; v = act(v);
+ *      geglu: W rows are interleaved in 16-row blocks (value block, gate block); the output
+ *             has N/2 columns = value * gelu_erf(gate);
+ *      v += residual[m][n] (fp32); store bf16 or fp32 at C[m*ldc + n].
+ * Constraints: K % 64 == 0, N % 16 == 0 (N % 32 for geglu), lda/ldc/ldr % 8 == 0.
+ * ------------------------------------------------------------------------------------ */
+typedef struct CcvGemm {
+    const void* A;
+    const uint16_t* W;
+    void* C;
+    const float* bias;     /* [N] or NULL */
+    const float* bias2;    /* [M / rows_per_batch, N] or NULL */
+    const float* residual; /* [M, ldr] fp32 or NULL (may alias C when out_f32) */
+    int32_t M, N, K, taps;
+    int32_t lda, ldc, ldr, ldb2; /* ldb2: row stride of bias2 (>= N) */
+    int32_t a_f32;          /* 0: A is bf16, 1: A is fp32 (converted on load) */
+    int32_t gather;         /* 0 linear, 1 conv3x3, 2 tconv3 */
+    int32_t out_h, out_w;   /* gather 1: output image size */
+    int32_t src_h, src_w;   /* gather 1: stored source image size (before upsample) */
+    int32_t stride;         /* gather 1: 1 or 2 */
+    int32_t upsample;       /* gather 1: 0/1 */
+    int32_t frames, hw;     /* gather 2: frames per clip, pixels per frame */
+    int32_t rows_per_batch; /* bias2 row = m / rows_per_batch */
+    int32_t act;            /* 0 none, 1 SiLU, 2 GELU(erf) */
+    int32_t geglu;          /* 0/1 */
+    int32_t out_f32;        /* 0: C is bf16, 1: C is fp32 */
+    float alpha;
+} CcvGemm;
+int ccv_gemm(const CcvGemm* p, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ccv_attn_fwd: O = softmax(Q K^T * scale [+ mask]) V, head dim 64, bf16 MFMA, fp32 online
+ * softmax; optionally a second key/value set attended separately and added with a gate.
+ *
+ * Replaces: xformers.ops.memory_efficient_attention (lvdm/modules/attention.py:177,189 incl.
+ * the gated image branch :205-209), the einsum attention (:105-129) used by the temporal
+ * transformers, and F.scaled_dot_product_attention with the boolean epipolar mask and the
+ * always-visible register tokens (model/modules/epipolar.py:86-99).
+ *
+ * Addressing (elements): X(batch i, token l, head h, d) =
+ *     X + (i / inner)*x_bso + (i % inner)*x_bsi + l*x_ls + h*64 + d
+ * so that a "batch" can be a frame of a clip (spatial), a pixel of a clip (temporal, token
+ * stride = pixels*C) or a clip (epipolar), and K/V shared by all frames use x_bsi = 0.
+ *
+ * mask_bits : NULL or [mask_nb, Lq, mask_words] uint32; bit j of word w set => key 32w+j visible.
+ * tile_flags: NULL or [mask_nb, ceil(Lq/128), ceil(Lk/64)] uint8; 0 => no visible key in that
+ *             (128 query x 64 key) tile (the tile is skipped; exact).
+ * kreg/vreg : NULL or [nreg, H*64] bf16 register-token keys/values, visible to every query.
+ * k2/v2     : NULL or second context (image tokens), length Lk2:  O += gate2 * attn(Q,K2,V2).
+ * ------------------------------------------------------------------------------------ */
+typedef struct CcvAttn {
+    const uint16_t* q; const uint16_t* k; const uint16_t* v; uint16_t* o;
+    int64_t q_bso, q_bsi, q_ls;
+    int64_t k_bso, k_bsi, k_ls;
+    int64_t v_bso, v_bsi, v_ls;
+    int64_t o_bso, o_bsi, o_ls;
+    int32_t B, inner, H, Lq, Lk;
+    float scale;
+    const uint16_t* k2; const uint16_t* v2;
+    int64_t k2_bso, k2_bsi, k2_ls;
+    int64_t v2_bso, v2_bsi, v2_ls;
+    int32_t Lk2;
+    float gate2;
+    const uint32_t* mask_bits; int64_t mask_bs; int32_t mask_words;
+    int32_t mask_nb;  /* masks exist for mask_nb batches; batch i uses mask i % mask_nb (CFG halves share) */
+    const uint8_t* tile_flags; int64_t flags_bs; int32_t flags_ktiles;
+    const uint16_t* kreg; const uint16_t* vreg; int32_t nreg;
+    int32_t variant;  /* 0: V via ds_read_tr16_b64, 1: V transposed while staging (debug/fallback) */
+} CcvAttn;
+int ccv_attn_fwd(const CcvAttn* p, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) (+SiLU) over token-major activations, fp32 statistics.
+ * Replaces GroupNormSpecific / nn.GroupNorm + nn.SiLU (lvdm/basics.py:78-91,
+ * openaimodel3d.py:151-153,175-177,255-266,561-563; attention.py:273,343).
+ *   x  : [instances*rows_per_instance, C] fp32 (x_f32) or bf16
+ *   y  : same shape, bf16
+ *   ws : workspace, ccv_groupnorm_ws_bytes(instances, C) bytes
+ * An instance is the set of rows that share statistics: one frame (h*w rows) for 4-D
+ * inputs, one clip (t*h*w rows) for the 5-D inputs of TemporalConvBlock/TemporalTransformer.
+ * Constraint: C % 64 == 0, C <= 4096.
+ * ------------------------------------------------------------------------------------ */
+int64_t ccv_groupnorm_ws_bytes(int32_t instances, int32_t C);
+int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta,
+                  int32_t instances, int32_t rows_per_instance, int32_t C, float eps, int32_t silu,
+                  void* ws, void* stream);
+
+/* LayerNorm over the last dim, fp32 in -> bf16 out; optional second output
+ * y2[r] = y[r] + addend[r % addend_rows] (bf16 [addend_rows, C]) used for the Pluecker-feature add `normed_x + pluker_embedding_features`
+ * (model/modules/modified_forwards.py:508-515).  Replaces nn.LayerNorm (attention.py:232-234).
+ * Constraint: C % 64 == 0, C <= 2048. */
+int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, const float* beta,
+                  int32_t rows, int32_t C, float eps,
+                  const uint16_t* addend, int32_t addend_rows, uint16_t* y2, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout / elementwise helpers on the path.
+ * ------------------------------------------------------------------------------------ */
+/* cat([x, c_concat], dim=1) + 'b c t h w -> (b t h w) c' (lvdm/models/ddpm3d.py:1270,
+ * openaimodel3d.py:587): x [b,c1,t,h,w], x2 [b,c2,t,h,w] (or NULL, c2=0) fp32 ->
+ * out [b*t*h*w, ldo] fp32, channels c1+c2..ldo-1 zero filled. */
+int ccv_pack_nchw_to_rows(const float* x, int32_t c1, const float* x2, int32_t c2,
+                          float* out, int32_t ldo, int32_t b, int32_t t, int32_t hw, void* stream);
+/* '(b t) c h w -> b c t h w' of the first c columns (openaimodel3d.py:623): in [rows, ldi] fp32. */
+int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out, int32_t c,
+                            int32_t b, int32_t t, int32_t hw, void* stream);
+/* torch.cat([h, skip], dim=1) on token-major fp32 rows (openaimodel3d.py:617). */
+int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out,
+                    int64_t rows, void* stream);
+/* fp32 -> bf16 (contexts, pose features) with an optional 'b c t h w -> (b t h w) c' transpose. */
+int ccv_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+int ccv_nchw_to_rows_bf16(const float* x, uint16_t* y, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);
+/* timestep_embedding (lvdm/models/utils_diffusion.py:8-28): t [n] fp32 -> [n, dim] bf16 (cos | sin). */
+int ccv_timestep_embedding(const float* t, uint16_t* out, int32_t n, int32_t dim, void* stream);
+/* out = SiLU(a + b) as bf16 (b may be NULL): the `emb` path of openaimodel3d.py:168-170,598. */
+int ccv_add_silu_bf16(const float* a, const float* b, uint16_t* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * ccv_ddim_cfg_step: classifier-free guidance + std rescale + DDIM update, fp32.
+ * Replaces lvdm/models/samplers/ddim.py:267,282-283,305-346 and
+ * lvdm/models/utils_diffusion.py:147-157.
+ *   e = e_uc + scale*(e_c - e_uc)                       (e_uc NULL => e = e_c)
+ *   e = gr * e*std(e_c)/std(e) + (1-gr)*e               (per sample, unbiased std)
+ *   x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);  x_prev = sqrt(a_prev) x0 + sqrt(max(1-a_prev-s^2,0)) e + s z
+ * coef: DEVICE pointer to 4 floats {a_t, a_prev, sigma_t, sqrt(1-a_t)} (device resident so a
+ * captured graph can be replayed for every step).  ws: n_samples*4 floats.  noise may be NULL.
+ * ------------------------------------------------------------------------------------ */
+int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* e_uc, const float* noise,
+                      float* x_prev, float* pred_x0, const float* coef,
+                      float scale, float guidance_rescale,
+                      int32_t n_samples, int64_t per_sample, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Epipolar mask preparation (once per clip).
+ * ccv_pack_mask: bool mask [B, Lq, Lk] (1 byte per element, as handed over in
+ * camera_condition["sample_locs_dict"], model/camcontexti2v.py:552) -> bit-packed rows
+ * [B, Lq, words] + tile flags [B, ceil(Lq/128), ceil(Lk/64)] (flags must be zeroed by caller).
+ * ccv_epipolar_mask_bits: the same packed form straight from the fundamental matrices
+ * F [B, T, T, 3, 3] (model/camcontexti2v.py:200-239), never materialising the bool tensor.
+ * ------------------------------------------------------------------------------------ */
+int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags,
+                  int32_t B, int32_t Lq, int32_t Lk, void* stream);
+int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags,
+                           int32_t B, int32_t T, int32_t H, int32_t W, int32_t downsample, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCV_H_ */

@@ -1,0 +1,364 @@
+"""Per-kernel parity tests of the HIP library (through the C ABI) on a real MI355X.
+
+Checker: plain torch fp32 math on the same (bf16-representable) inputs; for the DDIM
+step and the epipolar mask the CPU oracle.  Tolerances are stated per test: outputs that
+are stored as bf16 carry a 2^-9 relative rounding, fp32 outputs only the accumulation order.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import ops as o
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def assert_close(got, ref, tol, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert math.isfinite(err), f"{what}: non-finite output"
+    assert err <= tol * max(scale, 1e-6), f"{what}: max abs err {err:.4e} vs absmax {scale:.4e} (tol {tol})"
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (4096, 1280, 640), (2, 1280, 320), (16384, 320, 320),
+                                   (1000, 64, 128), (512, 2560, 1280)])
+def test_gemm_linear_bf16(ops, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    out = ops.gemm(a, w, bias=bias)
+    ref = a.float() @ w.float().t() + bias
+    assert_close(out, ref, 1e-2, f"linear {M}x{N}x{K}")
+    out32 = ops.gemm(a, w, bias=bias, out_f32=True)
+    assert_close(out32, ref, 2e-3, "linear fp32 out")
+
+
+def test_gemm_fp32_a_residual_act(ops):
+    M, N, K = 1024, 640, 320
+    a = rnd(M, K, seed=4, dtype=torch.float32)
+    w = rnd(N, K, seed=5, scale=0.05)
+    res = rnd(M, N, seed=6, dtype=torch.float32)
+    out = ops.gemm(a, w, residual=res, out_f32=True)
+    ref = a.to(torch.bfloat16).float() @ w.float().t() + res
+    assert_close(out, ref, 2e-3, "fp32 A + residual")
+    # in-place accumulation into the stream (C aliases residual)
+    stream = res.clone()
+    ops.gemm(a, w, residual=stream, out_f32=True, out=stream)
+    assert_close(stream, ref, 2e-3, "in-place residual")
+    for act, fn in ((ops.ACT_SILU, F.silu), (ops.ACT_GELU, F.gelu)):
+        out = ops.gemm(a, w, act=act)
+        assert_close(out, fn(a.to(torch.bfloat16).float() @ w.float().t()), 1e-2, f"act {act}")
+
+
+def test_gemm_bias2_strided(ops):
+    M, N, K, nb = 2048, 320, 320, 2
+    a, w = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.05)
+    table = rnd(nb, 1000, seed=9, dtype=torch.float32)
+    off = 200
+    out = ops.gemm(a, w, bias2=table[:, off:], ldb2=1000, rows_per_batch=M // nb)
+    ref = a.float() @ w.float().t() + table[:, off:off + N].repeat_interleave(M // nb, 0)
+    assert_close(out, ref, 1e-2, "bias2")
+
+
+def test_gemm_geglu(ops):
+    M, C = 1024, 320
+    a = rnd(M, C, seed=10)
+    w = rnd(8 * C, C, seed=11, scale=0.05)          # rows [0,4C) value, [4C,8C) gate
+    bias = rnd(8 * C, seed=12, dtype=torch.float32)
+    from camc2v_amd.pack import interleave_geglu
+    wp, bp = interleave_geglu(w, bias)
+    out = ops.gemm(a, wp, bias=bp, geglu=True)
+    full = a.float() @ w.float().t() + bias
+    val, gate = full.chunk(2, dim=-1)
+    assert out.shape == (M, 4 * C)
+    assert_close(out, val * F.gelu(gate), 1.5e-2, "geglu")
+
+
+@pytest.mark.parametrize("stride,upsample,a_f32", [(1, 0, False), (2, 0, True), (1, 1, True), (1, 0, True)])
+def test_gemm_conv3x3(ops, stride, upsample, a_f32):
+    from camc2v_amd.pack import pack_conv3x3
+    n, cin, cout, hs, ws = 3, 128, 192, 12, 10
+    x = rnd(n, cin, hs, ws, seed=13, dtype=torch.float32)
+    x = x.to(torch.bfloat16).float()  # bf16 representable
+    wt = rnd(cout, cin, 3, 3, seed=14, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    bias = rnd(cout, seed=15, dtype=torch.float32)
+    src = F.interpolate(x, scale_factor=2, mode="nearest") if upsample else x
+    ref = F.conv2d(src, wt, bias, stride=stride, padding=1)
+    oh, ow = ref.shape[-2:]
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous()
+    a = rows if a_f32 else rows.to(torch.bfloat16)
+    out = ops.gemm(a, pack_conv3x3(wt), k=cin, taps=9, m=n * oh * ow, bias=bias, gather=ops.GATHER_CONV3X3,
+                   conv=(oh, ow, hs, ws, stride, upsample), out_f32=True)
+    assert_close(out.reshape(n, oh, ow, cout).permute(0, 3, 1, 2), ref, 2e-3, "conv3x3")
+
+
+def test_gemm_tconv3(ops):
+    from camc2v_amd.pack import pack_tconv3
+    b, c, t, hw, cout = 2, 128, 16, 20, 128
+    x = rnd(b, c, t, hw, 1, seed=16, dtype=torch.float32).to(torch.bfloat16).float()
+    wt = rnd(cout, c, 3, 1, 1, seed=17, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    bias = rnd(cout, seed=18, dtype=torch.float32)
+    ref = F.conv3d(x, wt, bias, padding=(1, 0, 0))  # [b, cout, t, hw, 1]
+    rows = x[..., 0].permute(0, 2, 3, 1).reshape(-1, c).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_tconv3(wt), k=c, taps=3, bias=bias, gather=ops.GATHER_TCONV3, tconv=(t, hw), out_f32=True)
+    assert_close(out.reshape(b, t, hw, cout).permute(0, 3, 1, 2), ref[..., 0], 2e-3, "tconv3")
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from camc2v_amd.lib import CcvError
+    with pytest.raises(CcvError):
+        ops.gemm(rnd(64, 100), rnd(64, 100))          # K not a multiple of 64
+    with pytest.raises(CcvError):
+        ops.gemm(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))  # CPU tensors
+
+
+# ------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------
+def ref_attn(q, k, v, mask=None):
+    """q [B,Lq,H,64] k,v [B,Lk,H,64] fp32; mask bool [B,Lq,Lk]."""
+    sim = torch.einsum("bihd,bjhd->bhij", q, k) / 8.0
+    if mask is not None:
+        sim = sim.masked_fill(~mask[:, None], float("-inf"))
+    return torch.einsum("bhij,bjhd->bihd", sim.softmax(-1), v)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(3, 5, 1024, 1024), (2, 2, 200, 77), (4, 1, 16, 16), (1, 3, 130, 333)])
+def test_attention_plain(ops, variant, B, H, Lq, Lk):
+    q, k, v = rnd(B, Lq, H, 64, seed=20), rnd(B, Lk, H, 64, seed=21), rnd(B, Lk, H, 64, seed=22)
+    C = H * 64
+    out = ops.attention(q, k, v, B=B, inner=1, H=H, Lq=Lq, Lk=Lk, q_str=(Lq * C, 0, C), k_str=(Lk * C, 0, C),
+                        v_str=(Lk * C, 0, C), variant=variant)
+    ref = ref_attn(q.float(), k.float(), v.float())
+    assert_close(out.reshape(B, Lq, H, 64), ref, 1.5e-2, f"attention v{variant} {B},{H},{Lq},{Lk}")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_fused_qkv_and_dual_context(ops, variant):
+    """q/k/v as column slices of one fused [rows, 3C] projection; text + gated image context with
+    K/V shared by all frames of a clip (inner batch stride 0)."""
+    clips, frames, hw, H = 2, 4, 96, 2
+    C = H * 64
+    B = clips * frames
+    qkv = rnd(B * hw, 3 * C, seed=23)
+    out = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=hw, Lk=hw,
+                        q_str=(hw * 3 * C, 0, 3 * C), k_str=(hw * 3 * C, 0, 3 * C), v_str=(hw * 3 * C, 0, 3 * C),
+                        variant=variant)
+    x = qkv.float().reshape(B, hw, 3, H, 64)
+    assert_close(out.reshape(B, hw, H, 64), ref_attn(x[:, :, 0], x[:, :, 1], x[:, :, 2]), 1.5e-2, "fused qkv")
+
+    q = rnd(B * hw, C, seed=24)
+    kv_t = rnd(clips * 77, 2 * C, seed=25)     # text: per clip
+    kv_i = rnd(clips * frames * 16, 2 * C, seed=26)  # image: 16 tokens per frame
+    gate = 1.37
+    out = ops.attention(q, kv_t, kv_t[:, C:], B=B, inner=frames, H=H, Lq=hw, Lk=77,
+                        q_str=(frames * hw * C, hw * C, C), k_str=(77 * 2 * C, 0, 2 * C), v_str=(77 * 2 * C, 0, 2 * C),
+                        k2=kv_i, v2=kv_i[:, C:], k2_str=(frames * 16 * 2 * C, 16 * 2 * C, 2 * C),
+                        v2_str=(frames * 16 * 2 * C, 16 * 2 * C, 2 * C), Lk2=16, gate2=gate, variant=variant)
+    qf = q.float().reshape(B, hw, H, 64)
+    kt = kv_t.float().reshape(clips, 77, 2, H, 64).repeat_interleave(frames, 0)
+    ki = kv_i.float().reshape(B, 16, 2, H, 64)
+    ref = ref_attn(qf, kt[:, :, 0], kt[:, :, 1]) + gate * ref_attn(qf, ki[:, :, 0], ki[:, :, 1])
+    assert_close(out.reshape(B, hw, H, 64), ref, 1.5e-2, "dual context")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_temporal_strided(ops, variant):
+    """batch = (clip, pixel), tokens = frames with stride hw*C (token-major activations untouched)."""
+    clips, T, hw, H = 2, 16, 24, 3
+    C = H * 64
+    qkv = rnd(clips * T * hw, 3 * C, seed=27)
+    ld = 3 * C
+    out = torch.empty(clips * T * hw, C, dtype=torch.bfloat16, device=dev())
+    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=clips * hw, inner=hw, H=H, Lq=T, Lk=T,
+                  q_str=(T * hw * ld, ld, hw * ld), k_str=(T * hw * ld, ld, hw * ld), v_str=(T * hw * ld, ld, hw * ld),
+                  out=out, o_str=(T * hw * C, C, hw * C), variant=variant)
+    x = qkv.float().reshape(clips, T, hw, 3, H, 64).permute(0, 2, 1, 3, 4, 5).reshape(clips * hw, T, 3, H, 64)
+    ref = ref_attn(x[:, :, 0], x[:, :, 1], x[:, :, 2])
+    got = out.reshape(clips, T, hw, H, 64).permute(0, 2, 1, 3, 4).reshape(clips * hw, T, H, 64)
+    assert_close(got, ref, 1.5e-2, "temporal")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("L,density", [(1024, 0.04), (320, 0.3), (48, 0.5)])
+def test_attention_masked_register_tokens(ops, variant, L, density):
+    """Epipolar form: bit mask + tile flags + always-visible register tokens; mask shared by the
+    two halves of a CFG batch (mask_nb=1 while B=2).  Includes fully empty tiles and rows."""
+    B, H, nreg = 2, 2, 4
+    C = H * 64
+    g = torch.Generator().manual_seed(30)
+    mask = torch.rand(1, L, L, generator=g) < density
+    mask[:, :, : L // 3] &= (torch.rand(1, L, 1, generator=g) < 0.5)   # some rows see nothing in a band
+    if L >= 256:
+        mask[:, :128, 64:192] = False                                   # an empty 128x128 region
+        mask[:, 5] = False                                              # a row that only sees the registers
+    mask = mask.to(dev())
+    bits, flags = ops.pack_mask(mask)
+    qkv = rnd(B * L, 3 * C, seed=31)
+    kreg, vreg = rnd(nreg, C, seed=32), rnd(nreg, C, seed=33)
+    ld = 3 * C
+    out = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=(L * ld, 0, ld),
+                        k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1, tile_flags=flags,
+                        kreg=kreg, vreg=vreg, variant=variant)
+    x = qkv.float().reshape(B, L, 3, H, 64)
+    k = torch.cat([kreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)
+    v = torch.cat([vreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 2]], 1)
+    m = F.pad(mask.expand(B, -1, -1), (nreg, 0), value=True)
+    assert_close(out.reshape(B, L, H, 64), ref_attn(x[:, :, 0], k, v, m), 1.5e-2, f"masked L={L}")
+    # without flags (only the in-kernel word test) the result is identical
+    out2 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=(L * ld, 0, ld),
+                         k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1,
+                         kreg=kreg, vreg=vreg, variant=variant)
+    assert torch.equal(out, out2)
+
+
+def test_attention_softmax_rescale_spike(ops):
+    """Force the online-softmax rescale: one key tile carries a huge score late in the sequence."""
+    B, H, Lq, Lk = 1, 1, 64, 512
+    q, k, v = rnd(B, Lq, H, 64, seed=34), rnd(B, Lk, H, 64, seed=35), rnd(B, Lk, H, 64, seed=36)
+    k[0, 300, 0] = q[0, 7, 0] * 4.0     # spike for query 7 in tile 4
+    k[0, 450, 0] = q[0, 40, 0] * 6.0
+    out = ops.attention(q, k, v, B=B, inner=1, H=H, Lq=Lq, Lk=Lk, q_str=(Lq * 64, 0, 64), k_str=(Lk * 64, 0, 64),
+                        v_str=(Lk * 64, 0, 64))
+    assert_close(out.reshape(B, Lq, H, 64), ref_attn(q.float(), k.float(), v.float()), 1.5e-2, "spike")
+
+
+# ------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,inst,rpi,f32,silu", [(320, 6, 1024, True, True), (2560, 4, 16, True, True),
+                                                 (64, 2, 4096, False, False), (1280, 2, 1024, False, True),
+                                                 (960, 3, 100, True, False)])
+def test_groupnorm(ops, C, inst, rpi, f32, silu):
+    x = rnd(inst * rpi, C, seed=40, dtype=torch.float32 if f32 else torch.bfloat16) * 2.0 + 0.5
+    gamma = 1.0 + rnd(C, seed=41, dtype=torch.float32) * 0.1
+    beta = rnd(C, seed=42, dtype=torch.float32) * 0.1
+    y = ops.groupnorm(x, gamma, beta, instances=inst, eps=1e-5, silu=silu)
+    xr = x.float().reshape(inst, rpi, C).permute(0, 2, 1)     # [inst, C, rpi]
+    ref = F.group_norm(xr, 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert_close(y.reshape(inst, rpi, C), ref.permute(0, 2, 1), 1e-2, "groupnorm")
+
+
+@pytest.mark.parametrize("C", [64, 320, 512, 1280])
+def test_layernorm(ops, C):
+    rows = 1000
+    x = rnd(rows, C, seed=43, dtype=torch.float32) * 3 + 1
+    gamma = 1.0 + rnd(C, seed=44, dtype=torch.float32) * 0.1
+    beta = rnd(C, seed=45, dtype=torch.float32) * 0.1
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    assert_close(ops.layernorm(x, gamma, beta), ref, 8e-3, "layernorm")
+    add = rnd(rows // 2, C, seed=46)
+    y, y2 = ops.layernorm(x, gamma, beta, addend=add)
+    assert_close(y, ref, 8e-3, "layernorm y")
+    assert_close(y2, ref + add.float().repeat(2, 1), 8e-3, "layernorm y2")
+
+
+# ------------------------------------------------------------------------------------------
+# layout / elementwise / DDIM / masks
+# ------------------------------------------------------------------------------------------
+def test_layout_roundtrip(ops):
+    b, t, h, w = 2, 16, 8, 8
+    x = rnd(b, 4, t, h, w, seed=50, dtype=torch.float32)
+    c = rnd(b, 4, t, h, w, seed=51, dtype=torch.float32)
+    rows = ops.pack_nchw_to_rows(x, c, ldo=64)
+    ref = torch.cat([x, c], 1).permute(0, 2, 3, 4, 1).reshape(-1, 8)
+    assert torch.equal(rows[:, :8], ref) and float(rows[:, 8:].abs().max()) == 0.0
+    back = ops.unpack_rows_to_nchw(rows, 8, b, t, h, w)
+    assert torch.equal(back, torch.cat([x, c], 1))
+    a, bb = rnd(100, 64, seed=52, dtype=torch.float32), rnd(100, 128, seed=53, dtype=torch.float32)
+    assert torch.equal(ops.concat_rows(a, bb), torch.cat([a, bb], 1))
+    f = rnd(2, 320, 16, 4, 4, seed=54, dtype=torch.float32)
+    assert torch.equal(ops.nchw_to_rows_bf16(f), f.permute(0, 2, 3, 4, 1).reshape(-1, 320).to(torch.bfloat16))
+    assert torch.equal(ops.cast_bf16(a), a.to(torch.bfloat16))
+
+
+def test_timestep_embedding_and_add_silu(ops):
+    from oracle.unet_oracle import timestep_embedding
+    t = torch.tensor([999, 439, 39, 0, 8], dtype=torch.long)
+    got = ops.timestep_embedding(t.to(dev()), 320)
+    assert_close(got, timestep_embedding(t, 320), 6e-3, "timestep embedding")
+    a, b = rnd(7, 1280, seed=55, dtype=torch.float32), rnd(7, 1280, seed=56, dtype=torch.float32)
+    assert_close(ops.add_silu_bf16(a, b), F.silu(a + b), 6e-3, "add_silu")
+
+
+def test_ddim_cfg_step_vs_oracle_and_golden(ops, golden_dir):
+    from oracle import ddim_oracle
+    fx = np.load(os.path.join(golden_dir, "ddim.npz"))
+    tab = ddim_oracle.ddim_tables(25, 1.0)
+    x, e_c, e_uc = (torch.from_numpy(fx[k]).to(dev()) for k in ("step_x", "step_e_c", "step_e_uc"))
+    for index in (24, 7, 0):
+        z = torch.from_numpy(fx[f"step{index}_noise"]).to(dev())
+        coef = torch.tensor([tab["alphas"][index], tab["alphas_prev"][index], tab["sigmas"][index],
+                             tab["sqrt_one_minus_alphas"][index]], dtype=torch.float32, device=dev())
+        x_prev, x0 = ops.ddim_cfg_step(x, e_c, e_uc, z, coef, 7.5, 0.7)
+        assert_close(x_prev, torch.from_numpy(fx[f"step{index}_x_prev"]), 2e-5, "x_prev vs reference fixture")
+        assert_close(x0, torch.from_numpy(fx[f"step{index}_pred_x0"]), 2e-5, "pred_x0 vs reference fixture")
+    z = torch.from_numpy(fx["noguid_noise"]).to(dev())
+    coef = torch.tensor([tab["alphas"][3], tab["alphas_prev"][3], tab["sigmas"][3], tab["sqrt_one_minus_alphas"][3]],
+                        dtype=torch.float32, device=dev())
+    x_prev, _ = ops.ddim_cfg_step(x, e_c, None, z, coef, 1.0, 0.0)
+    assert_close(x_prev, torch.from_numpy(fx["noguid_x_prev"]), 2e-5, "no guidance")
+
+
+def test_pack_mask_matches_numpy(ops):
+    g = torch.Generator().manual_seed(60)
+    for (B, Lq, Lk) in ((2, 256, 256), (1, 130, 80), (1, 64, 16)):
+        m = torch.rand(B, Lq, Lk, generator=g) < 0.2
+        bits, flags = ops.pack_mask(m.to(dev()))
+        ref = np.packbits(m.numpy().astype(np.uint8), axis=-1, bitorder="little")
+        pad = (-ref.shape[-1]) % 4
+        ref = np.pad(ref, ((0, 0), (0, 0), (0, pad))).view(np.uint32).astype(np.int64)
+        assert np.array_equal(bits.cpu().numpy().view(np.uint32).astype(np.int64), ref)
+        kt, qt = (Lk + 63) // 64, (Lq + 127) // 128
+        mp = torch.zeros(B, qt * 128, kt * 64, dtype=torch.bool)
+        mp[:, :Lq, :Lk] = m
+        assert torch.equal(flags.cpu().bool(), mp.reshape(B, qt, 128, kt, 64).any(4).any(2))
+
+
+def test_epipolar_mask_bits_vs_oracle(ops, golden_dir):
+    """Native mask build from F.  Tolerance-budgeted: the GPU evaluates the same fp32 formula with
+    its own rounding of the 3-term dot products; flips are confined to pixels within an ulp of the
+    threshold.  Budget: <= 1e-4 of the set bits."""
+    from oracle import geometry_oracle
+    fx = np.load(os.path.join(golden_dir, "geometry.npz"))
+    for px, key in ((64, "F64"), (256, "F256")):
+        Fm = torch.from_numpy(fx[key])
+        for d in (8, 16, 32, 64):
+            H = px // d
+            if H * H * 16 > 4096:      # keep the CPU oracle side small
+                continue
+            ref = geometry_oracle.epipolar_mask(Fm, H, H, d)
+            bits, flags = ops.epipolar_mask_bits(Fm.to(dev()), 16, H, H, d)
+            refbits, refflags = ops.pack_mask(ref.to(dev()))
+            diff = (bits ^ refbits).cpu().numpy().view(np.uint32)
+            nflip = int(np.unpackbits(diff.view(np.uint8)).sum())
+            assert nflip <= 1e-4 * float(ref.sum()) + 1, f"px={px} d={d}: {nflip} flipped mask bits"
+            if nflip == 0:
+                assert torch.equal(flags, refflags)
