@@ -1,0 +1,113 @@
+"""Diffusion-process boundary of the hot path: DiffusionWrapper + the schedule/apply_model/sample_log
+slice of LatentDiffusion (reference lvdm/models/ddpm3d.py:125-188, 724-739, 992-1002, 1251-1320).
+
+Only what the sampler needs is here; training, losses, EMA, VAE and text/image encoders are outside the
+hot path.  Checkpoint keys keep the reference prefixes
+(``model.diffusion_model.*``, ``betas``, ``alphas_cumprod`` ...).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .config import instantiate_from_config
+from .lib import CcvError
+from .sampler import DDIMSampler, make_beta_schedule
+
+
+class DiffusionWrapper(nn.Module):
+    """Routes conditioning into the UNet (reference ddpm3d.py:1251-1320): 'hybrid' concatenates ``c_concat``
+    on the channel axis and ``c_crossattn`` on the token axis; all other cond keys pass through as kwargs."""
+
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+
+    def forward(self, x, t, c_concat=None, c_crossattn=None, c_adm=None, s=None, mask=None, **kwargs):
+        key = self.conditioning_key
+        if key is None:
+            return self.diffusion_model(x, t)
+        if key == "concat":
+            return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t, **kwargs)
+        if key == "crossattn":
+            return self.diffusion_model(x, t, context=torch.cat(list(c_crossattn), 1), **kwargs)
+        if key == "hybrid":
+            return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t,
+                                        context=torch.cat(list(c_crossattn), 1), **kwargs)
+        raise NotImplementedError(f"conditioning_key {key!r} is not used by the shipped configs")
+
+
+class LatentDiffusionCore(nn.Module):
+    """Schedule buffers + ``apply_model`` + ``sample_log``: what DDIMSampler needs from the model."""
+
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
+                 cosine_s=8e-3, parameterization="eps", conditioning_key=None, channels=3, image_size=256,
+                 temporal_length=None, use_dynamic_rescale=False, rescale_betas_zero_snr=False, **ignored):
+        super().__init__()
+        if parameterization != "eps" or use_dynamic_rescale or rescale_betas_zero_snr:
+            raise NotImplementedError("only eps-parameterised, statically scaled schedules are shipped")
+        self.parameterization = parameterization
+        self.use_dynamic_rescale = False
+        self.channels = channels
+        self.image_size = image_size if isinstance(image_size, (list, tuple)) else [image_size, image_size]
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.temporal_length = temporal_length if temporal_length is not None else getattr(
+            self.model.diffusion_model, "temporal_length", None)
+        betas = make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+        ac = np.cumprod(1.0 - betas, axis=0)
+        self.num_timesteps = int(timesteps)
+        f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+        self.register_buffer("betas", f32(betas))
+        self.register_buffer("alphas_cumprod", f32(ac))
+        self.register_buffer("alphas_cumprod_prev", f32(np.append(1.0, ac[:-1])))
+        self.register_buffer("sqrt_alphas_cumprod", f32(np.sqrt(ac)))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", f32(np.sqrt(1.0 - ac)))
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        shape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+        return (self.sqrt_alphas_cumprod[t].reshape(shape) * x_start
+                + self.sqrt_one_minus_alphas_cumprod[t].reshape(shape) * noise)
+
+    def _as_dict(self, cond):
+        if isinstance(cond, dict):
+            return cond
+        if not isinstance(cond, list):
+            cond = [cond]
+        return {("c_concat" if self.model.conditioning_key == "concat" else "c_crossattn"): cond}
+
+    def apply_model(self, x_noisy, t, cond, **kwargs):
+        out = self.model(x_noisy, t, **self._as_dict(cond), **kwargs)
+        return out[0] if isinstance(out, tuple) else out
+
+    def apply_model_pair(self, x, t, cond, uncond, **kwargs):
+        """Conditional and unconditional eps in ONE UNet forward on a 2b batch.  The two contexts may have
+        different lengths (cond: 77+256(1+N) tokens, uncond: 77+16t): they are handed over as a list and
+        only the cross-attention runs per half.  Everything that is not c_concat / c_crossattn must be
+        shared by the two halves (the sampler shares the camera dict; fs and flags come in kwargs)."""
+        c, uc = self._as_dict(cond), self._as_dict(uncond)
+        if self.model.conditioning_key != "hybrid":
+            return self.apply_model(x, t, c, **kwargs), self.apply_model(x, t, uc, **kwargs)
+        b = x.shape[0]
+        xc = torch.cat([torch.cat([x] + list(c["c_concat"]), 1), torch.cat([x] + list(uc["c_concat"]), 1)], 0)
+        ctx = [torch.cat(list(c["c_crossattn"]), 1), torch.cat(list(uc["c_crossattn"]), 1)]
+        extra = {k: v for k, v in c.items() if k not in ("c_concat", "c_crossattn")}
+        kw = dict(kwargs)
+        if kw.get("fs") is not None:
+            kw["fs"] = torch.cat([kw["fs"], kw["fs"]], 0)
+        out = self.model.diffusion_model(xc, torch.cat([t, t], 0), context=ctx, **extra, **kw)
+        return out[:b], out[b:]
+
+    @torch.no_grad()
+    def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):
+        if not ddim:
+            raise NotImplementedError("ancestral DDPM sampling is not on the generation path")
+        shape = (self.channels, self.temporal_length, *self.image_size)
+        return DDIMSampler(self).sample(ddim_steps, batch_size, shape, cond, verbose=False, **kwargs)
+
+
+__all__ = ["DiffusionWrapper", "LatentDiffusionCore", "CcvError"]

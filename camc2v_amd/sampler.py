@@ -1,0 +1,207 @@
+"""DDIM sampler with classifier-free guidance for the MI355X path.
+
+Same constructor / ``sample`` / ``ddim_sampling`` / ``p_sample_ddim`` signatures and the same
+schedule arithmetic as the reference sampler (``lvdm/models/samplers/ddim.py:10-346``,
+``lvdm/models/utils_diffusion.py:31-91,147-157``), re-designed for the device:
+
+  * the per-step coefficients live in one device table, so a step needs no host->device scalar
+    traffic (the reference rebuilds ``torch.full`` tensors from python floats every step);
+  * guidance, the std rescale and the x_{t-1} update are one fused HIP launch pair
+    (``ccv_ddim_cfg_step``);
+  * when the model offers ``apply_model_pair`` the conditional and unconditional passes run as
+    ONE UNet forward on a 2b batch (weights are read once per step instead of twice);
+  * the camera dict is shared with the unconditional branch by reference (the reference
+    deep-copies the 268 MB mask every step, ddim.py:258-260).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .lib import CcvError
+
+
+# ---- schedule (host side, float64/float32 exactly as the reference mixes them) ------------------
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    if schedule == "linear":
+        return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    if schedule == "sqrt_linear":
+        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
+    if schedule == "sqrt":
+        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64) ** 0.5
+    if schedule == "cosine":
+        ts = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
+        a = np.cos(ts / (1 + cosine_s) * np.pi / 2) ** 2
+        a = a / a[0]
+        return np.clip(1 - a[1:] / a[:-1], 0, 0.999)
+    raise ValueError(f"schedule '{schedule}' unknown.")
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        steps = np.asarray(list(range(0, num_ddpm_timesteps, c))) + 1
+    elif ddim_discr_method == "uniform_trailing":
+        c = num_ddpm_timesteps / num_ddim_timesteps
+        steps = np.flip(np.round(np.arange(num_ddpm_timesteps, 0, -c))).astype(np.int64) - 1
+    elif ddim_discr_method == "quad":
+        steps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int) + 1
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    if verbose:
+        print(f"Selected timesteps for ddim sampler: {steps}")
+    return steps
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """alphacums: fp32 tensor (CPU).  Returns fp32 numpy arrays (sigmas, alphas, alphas_prev): the values
+    p_sample_ddim ends up using after its ``torch.full`` rounding (see oracle/ddim_oracle.py)."""
+    ac = alphacums.detach().float().cpu()
+    a = ac[torch.as_tensor(np.ascontiguousarray(ddim_timesteps))]
+    a_prev = torch.tensor([ac[0].item()] + ac[torch.as_tensor(np.ascontiguousarray(ddim_timesteps[:-1]))].tolist(),
+                          dtype=torch.float64)
+    a64 = a.double()
+    sig = eta * torch.sqrt((1 - a_prev) / (1 - a64) * (1 - a64 / a_prev))
+    return sig.float().numpy(), a.numpy(), a_prev.float().numpy()
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.counter = 0
+
+    def register_buffer(self, name, attr):
+        if isinstance(attr, torch.Tensor):
+            attr = attr.to(self.model.device)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        ac = self.model.alphas_cumprod
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        if getattr(self.model, "use_dynamic_rescale", False):
+            raise NotImplementedError("use_dynamic_rescale is not used by any shipped config")
+        f32 = lambda t: t.detach().clone().float()
+        self.register_buffer("betas", f32(self.model.betas))
+        self.register_buffer("alphas_cumprod", f32(ac))
+        self.register_buffer("alphas_cumprod_prev", f32(self.model.alphas_cumprod_prev))
+        sig, a, a_prev = make_ddim_sampling_parameters(ac, self.ddim_timesteps, ddim_eta, verbose)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, a_prev
+        self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - torch.from_numpy(a)).numpy()
+        # device-resident per-step coefficient rows: (a_t, a_prev, sigma_t, sqrt(1 - a_t))
+        table = np.stack([a, a_prev, sig, self.ddim_sqrt_one_minus_alphas], axis=1).astype(np.float32)
+        self.register_buffer("ddim_coef", torch.from_numpy(table).contiguous())
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0.0, mask=None, x0=None, temperature=1.0, noise_dropout=0.0,
+               score_corrector=None, corrector_kwargs=None, verbose=True, schedule_verbose=False, x_T=None,
+               log_every_t=100, unconditional_guidance_scale=1.0, unconditional_conditioning=None, precision=None,
+               fs=None, timestep_spacing="uniform", guidance_rescale=0.0, **kwargs):
+        if conditioning is not None and isinstance(conditioning, dict):
+            first = conditioning[list(conditioning.keys())[0]]
+            cbs = first.shape[0] if hasattr(first, "shape") else first[0].shape[0]
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
+        size = (batch_size, *shape)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                  noise_dropout=noise_dropout, temperature=temperature,
+                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
+                                  log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose,
+                                  precision=precision, fs=fs, guidance_rescale=guidance_rescale, **kwargs)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100,
+                      temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1.0, unconditional_conditioning=None, verbose=True, precision=None,
+                      fs=None, guidance_rescale=0.0, injected_noise=None, **kwargs):
+        """``injected_noise``: optional sequence of per-step N(0,1) tensors used instead of torch.randn
+        (parity tests; the reference draws with noise_like, lvdm/common.py:31-34)."""
+        if ddim_use_original_steps or timesteps is not None:
+            raise NotImplementedError("only the DDIM sub-schedule is supported (ddim_use_original_steps=False)")
+        if mask is not None:
+            raise NotImplementedError("mask/x0 blending is not on the generation path of 02_generate_videos.py")
+        for flag in ("paste_overlap_frames", "noise_shaping"):
+            if kwargs.get(flag):
+                raise NotImplementedError(f"{flag} belongs to the autoregressive demo path, not to the hot path")
+        device = self.model.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).float().contiguous()
+        steps = self.ddim_timesteps
+        total = steps.shape[0]
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        kwargs.pop("clean_cond", None)
+        # every timestep tensor is built up front: no host->device traffic inside the loop
+        ts_all = torch.from_numpy(np.ascontiguousarray(np.flip(steps))).to(device=device, dtype=torch.long)
+        ts_all = ts_all[:, None].expand(total, b).contiguous()
+        for i in range(total):
+            index = total - i - 1
+            z = injected_noise[i].to(device).float().contiguous() if injected_noise is not None else None
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts_all[i], index=index, temperature=temperature,
+                                              noise_dropout=noise_dropout, score_corrector=score_corrector,
+                                              corrector_kwargs=corrector_kwargs, quantize_denoised=quantize_denoised,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning, mask=mask, x0=x0,
+                                              fs=fs, guidance_rescale=guidance_rescale, noise=z, **kwargs)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        if kwargs.get("paste_cond_frame"):
+            idx = cond["c_cond_frame_index"]
+            bi = torch.arange(img.shape[0], device=device)
+            img = img.clone()
+            img[bi, :, idx] = cond["origin_z_0"][bi, :, idx]
+        return img, intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1.0, unconditional_conditioning=None, uc_type=None,
+                      conditional_guidance_scale_temporal=None, mask=None, x0=None, guidance_rescale=0.0,
+                      noise=None, **kwargs):
+        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.0:
+            raise NotImplementedError("original-step / quantised / corrected / dropout sampling is not on the hot path")
+        if getattr(self.model, "parameterization", "eps") != "eps":
+            raise NotImplementedError("only the eps parameterisation is used by the shipped configs")
+        if kwargs.get("camera_cfg", 1.0) != 1.0:
+            raise NotImplementedError("camera_cfg != 1.0 (third forward) is off by default and not built yet")
+        x = x.float().contiguous()
+        e_uc = None
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.0:
+            e_c = self.model.apply_model(x, t, c, **kwargs)
+        else:
+            if not isinstance(c, (dict, torch.Tensor)):
+                raise NotImplementedError
+            if kwargs.get("enable_camera_condition") and isinstance(c, dict) and "camera_condition" in c:
+                # shared by reference; the marker key the reference sets on its copy is kept (ddim.py:259-260)
+                uc_cam = dict(c["camera_condition"])
+                uc_cam["is_uc"] = True
+                unconditional_conditioning["camera_condition"] = uc_cam
+            pair = getattr(self.model, "apply_model_pair", None)
+            if pair is not None:
+                e_c, e_uc = pair(x, t, c, unconditional_conditioning, **kwargs)
+            else:
+                e_c = self.model.apply_model(x, t, c, **kwargs)
+                e_uc = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
+        if noise is None and float(self.ddim_sigmas[index]) != 0.0:
+            shape = (1, *x.shape[1:]) if repeat_noise else x.shape
+            noise = torch.randn(shape, device=x.device).expand(x.shape).contiguous()
+        if noise is not None and temperature != 1.0:
+            noise = noise * temperature
+        x_prev, pred_x0 = ops.ddim_cfg_step(x, e_c.float().contiguous(), None if e_uc is None else e_uc.float().contiguous(),
+                                            noise, self.ddim_coef[index], unconditional_guidance_scale, guidance_rescale)
+        if kwargs.get("paste_cond_frame"):
+            raise NotImplementedError("paste_cond_frame inside the step is not on the generation path")
+        return x_prev, pred_x0
+
+
+__all__ = ["DDIMSampler", "make_beta_schedule", "make_ddim_timesteps", "make_ddim_sampling_parameters", "CcvError"]

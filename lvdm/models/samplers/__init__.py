@@ -1,0 +1,1 @@
+"""Import-path shim: the reference's yaml configs name classes by these dotted paths."""

@@ -24,6 +24,31 @@ import torch.nn.functional as F
 
 TEXT_LEN = 77  # CrossAttention.text_context_len, lvdm/modules/attention.py:49
 
+# Optional operand rounding.  None = exact fp32 restatement (the oracle proper).  With
+# torch.bfloat16 every matmul / conv / attention operand is rounded to bf16 first (fp32
+# accumulation), which is the arithmetic contract of the HIP path: tests use it to separate
+# "bf16 operands" error from implementation error.
+OPERAND_DTYPE = None
+
+
+def _r(x):
+    return x if OPERAND_DTYPE is None else x.to(OPERAND_DTYPE).float()
+
+
+class operand_rounding:
+    """with operand_rounding(torch.bfloat16): ...  (restores the previous setting on exit)"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global OPERAND_DTYPE
+        self.prev, OPERAND_DTYPE = OPERAND_DTYPE, self.dtype
+
+    def __exit__(self, *exc):
+        global OPERAND_DTYPE
+        OPERAND_DTYPE = self.prev
+
 
 # --------------------------------------------------------------------------
 # topology
@@ -109,7 +134,7 @@ def timestep_embedding(t, dim, max_period=10000):
 
 
 def _lin(sd, p, x, bias=True):
-    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"] if bias and (p + ".bias") in sd else None)
+    return F.linear(_r(x), _r(sd[p + ".weight"]), sd[p + ".bias"] if bias and (p + ".bias") in sd else None)
 
 
 def _gn(sd, p, x, eps):
@@ -127,11 +152,11 @@ def _heads(t, h):
 
 def _attend(q, k, v, heads, mask=None):
     """softmax(q k^T / sqrt(d)) v, fp32.  q:[b,n,C] k,v:[b,m,C]; mask bool [b,n,m] (True = keep)."""
-    qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
+    qh, kh, vh = _heads(_r(q), heads), _heads(_r(k), heads), _heads(_r(v), heads)
     sim = torch.einsum("bhid,bhjd->bhij", qh, kh) * (qh.shape[-1] ** -0.5)
     if mask is not None:
         sim = sim.masked_fill(~mask[:, None], float("-inf"))
-    out = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), vh)
+    out = torch.einsum("bhij,bhjd->bhid", _r(sim.softmax(-1)), vh)
     b, h, n, d = out.shape
     return out.permute(0, 2, 1, 3).reshape(b, n, h * d)
 
@@ -198,21 +223,21 @@ def temporal_conv_block(sd, p, x5):
         q = f"{p}.conv{i}"
         last = "2" if i == 1 else "3"  # conv1 has no Dropout slot (openaimodel3d.py:255-266)
         h = F.silu(_gn(sd, q + ".0", h, 1e-5))
-        h = F.conv3d(h, sd[f"{q}.{last}.weight"], sd[f"{q}.{last}.bias"], padding=(1, 0, 0))
+        h = F.conv3d(_r(h), _r(sd[f"{q}.{last}.weight"]), sd[f"{q}.{last}.bias"], padding=(1, 0, 0))
     return x5 + h
 
 
 def res_block(sd, p, x, emb, b, temporal_conv):
     """ResBlock._forward, openaimodel3d.py:210-236.  x: [(b t), c, h, w]."""
     h = F.silu(_gn(sd, p + ".in_layers.0", x, 1e-5))
-    h = F.conv2d(h, sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
+    h = F.conv2d(_r(h), _r(sd[p + ".in_layers.2.weight"]), sd[p + ".in_layers.2.bias"], padding=1)
     e = _lin(sd, p + ".emb_layers.1", F.silu(emb))
-    h = h + e[:, :, None, None]
+    h = _r(h + e[:, :, None, None])
     h = F.silu(_gn(sd, p + ".out_layers.0", h, 1e-5))
-    h = F.conv2d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
+    h = F.conv2d(_r(h), _r(sd[p + ".out_layers.3.weight"]), sd[p + ".out_layers.3.bias"], padding=1)
     if (p + ".skip_connection.weight") in sd:
         w = sd[p + ".skip_connection.weight"]
-        x = F.conv2d(x, w, sd[p + ".skip_connection.bias"], padding=w.shape[-1] // 2)
+        x = F.conv2d(_r(x), _r(w), sd[p + ".skip_connection.bias"], padding=w.shape[-1] // 2)
     h = x + h
     if temporal_conv and (p + ".temopral_conv.conv1.0.weight") in sd:
         bt, c, hh, ww = h.shape
@@ -251,7 +276,7 @@ def temporal_transformer(sd, p, x5, heads, depth, cam):
 
     def proj(name, z):
         w = sd[f"{p}.{name}.weight"]
-        return F.linear(z, w.reshape(w.shape[0], w.shape[1]), sd[f"{p}.{name}.bias"])
+        return F.linear(_r(z), _r(w.reshape(w.shape[0], w.shape[1])), sd[f"{p}.{name}.bias"])
 
     s = proj("proj_in", s)
     inner = s.shape[-1]
@@ -344,7 +369,7 @@ def unet_forward(sd, cfg, x, timesteps, context, fs=None, camera_condition=None,
             p = f"{prefix}.{j}"
             kind = layer[0]
             if kind == "conv_in":
-                h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+                h = F.conv2d(_r(h), _r(sd[p + ".weight"]), sd[p + ".bias"], padding=1)
             elif kind == "res":
                 h = res_block(sd, p, h, emb, b, tconv)
             elif kind == "spatial":
@@ -355,10 +380,10 @@ def unet_forward(sd, cfg, x, timesteps, context, fs=None, camera_condition=None,
                 h5 = temporal_transformer(sd, p, h5, layer[2], depth, cam_for(ds, hh, feature_id))
                 h = h5.permute(0, 2, 1, 3, 4).reshape(bt, c, hh, ww)
             elif kind == "down":
-                h = F.conv2d(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)
+                h = F.conv2d(_r(h), _r(sd[p + ".op.weight"]), sd[p + ".op.bias"], stride=2, padding=1)
             elif kind == "up":
                 h = F.interpolate(h, scale_factor=2, mode="nearest")
-                h = F.conv2d(h, sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
+                h = F.conv2d(_r(h), _r(sd[p + ".conv.weight"]), sd[p + ".conv.bias"], padding=1)
         return h
 
     hs = []
@@ -377,7 +402,7 @@ def unet_forward(sd, cfg, x, timesteps, context, fs=None, camera_condition=None,
         h = torch.cat([h, hs.pop()], dim=1)
         h = run(layers, f"output_blocks.{i}", h, topo["output_ds"][i])
     y = F.silu(_gn(sd, "out.0", h, 1e-5))
-    y = F.conv2d(y, sd["out.2.weight"], sd["out.2.bias"], padding=1)
+    y = F.conv2d(_r(y), _r(sd["out.2.weight"]), sd["out.2.bias"], padding=1)
     return y.reshape(b, t, y.shape[1], H, W).permute(0, 2, 1, 3, 4)
 
 

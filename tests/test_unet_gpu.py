@@ -1,0 +1,173 @@
+"""End-to-end parity of the HIP UNet / sampler on MI355X against (a) fixtures produced by RUNNING THE
+REFERENCE (tests/golden/unet_small.npz) and (b) the CPU oracle on the same seeded weights.
+
+Stated tolerance per UNet forward (bf16 GEMM/attention operands; fp32 accumulation, residual stream,
+norms and softmax), on the seeded N(0, 0.02) weights of the fixtures:
+    relative L2 error <= 7e-2   and   max |err| <= 1.2e-1 * max |ref|.
+Why this loose: the randomly initialised network amplifies rounding noise ~40x.  The CPU oracle run with
+every matmul operand rounded to bf16 (oracle.unet_oracle.operand_rounding) deviates from the fp32 reference
+by rel-L2 4.2e-2 on the same inputs, the HIP path by 4.6e-2; `test_error_is_bf16_rounding_not_implementation`
+asserts that the HIP error stays within 1.6x of that emulated floor, and tests/test_ops_gpu.py pins every
+kernel separately to ~1e-2 of the output range.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+REL_L2, MAX_REL = 7e-2, 1.2e-1
+
+
+def _check(got, ref, what, rel_l2=REL_L2, max_rel=MAX_REL):
+    got, ref = torch.as_tensor(got).float().cpu(), torch.as_tensor(ref).float().cpu()
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    l2 = ((got - ref).norm() / ref.norm()).item()
+    mx = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f"[parity] {what}: rel_l2={l2:.3e} max_rel={mx:.3e}")
+    assert l2 <= rel_l2 and mx <= max_rel, f"{what}: rel_l2={l2:.3e} (tol {rel_l2}), max_rel={mx:.3e} (tol {max_rel})"
+
+
+def _unbits(bits, L):
+    return torch.from_numpy(np.unpackbits(bits, axis=-1, bitorder="little")[..., :L].astype(bool))
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle.golden_inputs import SEED, SMALL_CFG, small_inputs
+    from oracle.unet_oracle import seeded_state_dict
+    from utils.utils import instantiate_from_config
+    dev = torch.device("cuda:0")
+    fx = dict(np.load(os.path.join(golden_dir, "unet_small.npz")))
+    man = json.load(open(os.path.join(golden_dir, "unet_small_manifest.json")))
+    sd = seeded_state_dict(man, SEED)
+    unet = instantiate_from_config({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG})
+    unet.enable_camera_conditioning(dict(origin_h=64, origin_w=64, is_3d_full_attn=False, num_register_tokens=4,
+                                         attention_resolution=[8, 4, 2, 1], compression_factor=1))
+    unet.load_state_dict(sd, strict=True)   # reference checkpoint layout, strict
+    unet = unet.to(dev).eval()
+    inp = small_inputs()
+    L = {8: 16 * 64, 16: 16 * 16, 32: 16 * 4, 64: 16}
+    masks = {d: _unbits(fx[f"mask_d{d}_bits"], L[d]) for d in L}
+    to = lambda t: t.to(dev)
+    cam = dict(pluker_embedding_features=[to(f) for f in inp["feats"]],
+               sample_locs_dict={d: to(m) for d, m in masks.items()},
+               cond_frame_index=torch.zeros(2, dtype=torch.long, device=dev), add_type="add_to_main_branch")
+    gin = {k: (to(v) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    return unet, fx, sd, inp, gin, cam, masks
+
+
+def test_no_camera_per_frame_context(small):
+    unet, fx, _, _, g, _, _ = small
+    y = unet(g["x"], g["t"], context=g["ctx_pf"], fs=g["fs"], camera_condition=None)
+    _check(y, fx["y_nocam_pf"], "no camera, per-frame ctx vs reference fixture")
+
+
+def test_error_is_bf16_rounding_not_implementation(small):
+    """HIP-vs-fp32 error must be explained by bf16 operand rounding: compare with the oracle run under the same
+    arithmetic contract (operands rounded to bf16, fp32 accumulate)."""
+    from oracle import unet_oracle as uo
+    from oracle.golden_inputs import SMALL_CFG
+    unet, fx, sd, inp, g, cam, masks = small
+    ref = torch.from_numpy(fx["y_cam_rep"])
+    cam_cpu = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks, add_type="add_to_main_branch")
+    with uo.operand_rounding(torch.bfloat16):
+        emu = uo.unet_forward(sd, SMALL_CFG, inp["x"], inp["t"], inp["ctx_rep"], inp["fs"], cam_cpu)
+    y = unet(g["x"], g["t"], context=g["ctx_rep"], fs=g["fs"], camera_condition=cam).cpu()
+    e_emu = ((emu - ref).norm() / ref.norm()).item()
+    e_hip = ((y - ref).norm() / ref.norm()).item()
+    print(f"[parity] bf16-emulated oracle rel_l2={e_emu:.3e}; HIP rel_l2={e_hip:.3e}")
+    assert e_hip <= 1.6 * e_emu + 2e-3
+
+
+def test_camera_repeat_context(small):
+    unet, fx, _, _, g, cam, _ = small
+    y = unet(g["x"], g["t"], context=g["ctx_rep"], fs=g["fs"], camera_condition=cam, enable_camera_condition=True, split="val")
+    _check(y, fx["y_cam_rep"], "camera, repeated ctx vs reference fixture")
+
+
+def test_camera_per_frame_context(small):
+    unet, fx, _, _, g, cam, _ = small
+    y = unet(g["x"], g["t"], context=g["ctx_pf"], fs=g["fs"], camera_condition=cam)
+    _check(y, fx["y_cam_pf"], "camera, per-frame ctx vs reference fixture")
+
+
+def test_other_add_type_nomask_default_fs(small):
+    unet, fx, _, _, g, cam, _ = small
+    one = lambda t: t[:1].contiguous()
+    cam1 = dict(cam, pluker_embedding_features=[one(f) for f in cam["pluker_embedding_features"]],
+                sample_locs_dict={d: one(m) for d, m in cam["sample_locs_dict"].items()})
+    y = unet(one(g["x"]), one(g["t"]), context=one(g["ctx_rep"]), fs=one(g["fs"]),
+             camera_condition=dict(cam1, add_type="add_into_temporal_attn"))
+    _check(y, fx["y_cam_other_addtype"], "other add_type vs reference fixture")
+    y = unet(one(g["x"]), one(g["t"]), context=one(g["ctx_rep"]), fs=one(g["fs"]),
+             camera_condition=dict(cam1, sample_locs_dict=None))
+    _check(y, fx["y_cam_nomask"], "camera without masks vs reference fixture")
+    y = unet(one(g["x"]), one(g["t"]), context=one(g["ctx_pf"]), fs=None, camera_condition=None)
+    _check(y, fx["y_default_fs"], "default fs vs reference fixture")
+
+
+def test_cfg_pair_equals_two_forwards(small):
+    """One 2b-batch forward with a list of contexts == two separate forwards (bit exact per half is not
+    required: tile selection may differ with M; same tolerance as everything else, in practice ~1e-3)."""
+    unet, fx, _, _, g, cam, _ = small
+    y_c = unet(g["x"], g["t"], context=g["ctx_rep"], fs=g["fs"], camera_condition=cam)
+    y_u = unet(g["x"], g["t"], context=g["ctx_pf"], fs=g["fs"], camera_condition=cam)
+    x2 = torch.cat([g["x"], g["x"]], 0)
+    y2 = unet(x2, torch.cat([g["t"], g["t"]]), context=[g["ctx_rep"], g["ctx_pf"]], fs=torch.cat([g["fs"], g["fs"]]),
+              camera_condition=cam)
+    _check(y2[:2], y_c, "pair/cond half", 2e-2, 5e-2)
+    _check(y2[2:], y_u, "pair/uncond half", 2e-2, 5e-2)
+    _check(y2[:2], fx["y_cam_rep"], "pair/cond half vs reference fixture")
+
+
+def test_native_packed_masks_equal_bool_masks(small):
+    """camera_condition['sample_locs_packed'] (bit-packed masks built on the GPU) == the bool-mask path."""
+    from camc2v_amd import ops
+    unet, fx, _, _, g, cam, _ = small
+    packed = {d: ops.pack_mask(m) for d, m in cam["sample_locs_dict"].items()}
+    cam_p = dict(cam, sample_locs_dict=None, sample_locs_packed=packed)
+    y = unet(g["x"], g["t"], context=g["ctx_rep"], fs=g["fs"], camera_condition=cam_p)
+    _check(y, fx["y_cam_rep"], "packed masks vs reference fixture")
+
+
+def test_ddim_three_steps_vs_reference_fixture(small):
+    """3 DDIM steps, CFG 7.5, rescale 0.7, eta 1 with the reference's noise draws injected."""
+    from camc2v_amd.diffusion import LatentDiffusionCore
+    from oracle.golden_inputs import SMALL_CFG
+    unet, fx, sd, _, g, cam, _ = small
+    core = LatentDiffusionCore({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG},
+                               linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4,
+                               image_size=[8, 8], temporal_length=16)
+    core.model.diffusion_model = unet          # reuse the loaded network
+    core = core.to("cuda:0")
+    cond = dict(c_concat=[g["c_concat"]], c_crossattn=[g["ctx_rep"]], camera_condition=cam)
+    uncond = dict(c_concat=[g["c_concat"]], c_crossattn=[g["ctx_pf"]])
+    noises = [torch.from_numpy(n) for n in fx["traj_noises"]]
+    samples, _ = core.sample_log(cond, 2, True, 3, eta=1.0, x_T=torch.from_numpy(fx["traj_x_T"]),
+                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uncond,
+                                 timestep_spacing="uniform_trailing", guidance_rescale=0.7, fs=g["fs"],
+                                 enable_camera_condition=True, injected_noise=noises)
+    assert uncond["camera_condition"]["is_uc"] is True
+    _check(samples, fx["traj_x0"], "3-step DDIM trajectory vs reference fixture", 1e-1, 2e-1)
+
+
+def test_module_level_api(small):
+    """Reference-shaped module entry points (CrossAttention / FeedForward take [b, n, C] like the reference's)."""
+    from oracle import unet_oracle
+    unet, _, sd, _, _, _, _ = small
+    blk = unet.input_blocks[1][1].transformer_blocks[0]
+    p = "input_blocks.1.1.transformer_blocks.0"
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 50, 64, generator=g)
+    ctx = torch.randn(3, 77 + 16, 1024, generator=g)
+    _check(blk.attn1(x.cuda()), unet_oracle.cross_attention(sd, p + ".attn1", x, None, 1, False), "attn1 module")
+    _check(blk.attn2(x.cuda(), context=ctx.cuda()),
+           unet_oracle.cross_attention(sd, p + ".attn2", x, ctx, 1, True), "attn2 module")
+    _check(blk.ff(x.cuda()), unet_oracle.feed_forward(sd, p + ".ff", x), "ff module")
