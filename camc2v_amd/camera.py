@@ -1,0 +1,79 @@
+"""Once-per-clip camera geometry that feeds the hot path.
+
+Pose algebra (a few hundred 4x4 / 3x3 products per clip) runs as small batched torch linalg on
+the device; the expensive part -- turning the pairwise fundamental matrices into the
+(T*H*W)^2 epipolar visibility masks -- is the HIP kernel ``ccv_epipolar_mask_bits``, which writes
+the bit-packed rows and tile flags the attention kernel consumes and never materialises the
+268 MB boolean tensor the reference builds (model/camcontexti2v.py:200-271).
+
+Reference anchors: model/base.py:176-199 (get_relative_pose), model/camcontexti2v.py:172-198
+(pairs, fundamental matrix), :273-278 (perturbation), :525-572 (assembly).
+"""
+import torch
+
+from . import ops
+
+
+def relative_c2w(w2c, cond_frame_index, trace_scale_factor=1.0):
+    """w2c [b,t,4,4] -> c2w relative to the conditioning frame ('left' mode), translation scaled."""
+    c2w = torch.linalg.inv(w2c.float())
+    b = c2w.shape[0]
+    first = c2w[torch.arange(b, device=c2w.device), cond_frame_index].unsqueeze(1)
+    rel = torch.linalg.inv(first) @ c2w
+    rel[:, :, :3, 3] = rel[:, :, :3, 3] * trace_scale_factor
+    return rel
+
+
+def pairwise_fundamental(K, rel_c2w, perturb_zero_translation=True, generator=None, noise=None):
+    """K [b,t,3,3] (pixel intrinsics), rel_c2w [b,t,4,4] -> F [b,t1,t2,3,3].
+
+    Pair (t1,t2) uses inv(RT[t2]) @ RT[t1]; E = t x R (column-wise cross product); F = K^-T E K^-1.
+    Exactly-zero translations (same-frame pairs) are replaced by 1e-6 * N(0,1) as the reference does when
+    ``add_small_perturbation_on_zero_T`` is set (``noise`` overrides the draw for reproducible tests)."""
+    pairs = torch.linalg.inv(rel_c2w)[:, None] @ rel_c2w[:, :, None]
+    R, t = pairs[..., :3, :3], pairs[..., :3, 3:4]
+    if perturb_zero_translation:
+        if noise is None:
+            noise = torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=generator)
+        zero = (t.abs() < 1e-6).all(dim=-2, keepdim=True)
+        t = torch.where(zero, noise.to(t) * 1e-6, t)
+    E = torch.cross(t.expand_as(R), R, dim=-2)
+    K_inv = torch.linalg.inv(K.float().unsqueeze(1))
+    return K_inv.transpose(-1, -2) @ E @ K_inv
+
+
+def epipolar_masks_packed(F, T, H_px, W_px, attention_resolution=(8, 4, 2, 1)):
+    """F [b,T,T,3,3] -> {8*ds: (bits int32 [b, L, L/32], flags uint8 [b, L/128, L/64])}, L = T*(H_px/8ds)*(W_px/8ds)."""
+    out = {}
+    for ds in attention_resolution:
+        d = int(8 * ds)
+        out[d] = ops.epipolar_mask_bits(F, T, H_px // d, W_px // d, d)
+    return out
+
+
+def camera_condition(K, w2c, cond_frame_index, H_px, W_px, pluker_features=None, add_type="add_to_main_branch",
+                     attention_resolution=(8, 4, 2, 1), trace_scale_factor=1.0, perturb=True, generator=None, noise=None):
+    """The dict the UNet takes as ``camera_condition`` (reference model/camcontexti2v.py:565-570), with the
+    masks in packed form under ``sample_locs_packed`` (``sample_locs_dict`` stays available for bool masks)."""
+    rel = relative_c2w(w2c, cond_frame_index, trace_scale_factor)
+    F = pairwise_fundamental(K, rel, perturb, generator, noise)
+    return {
+        "pluker_embedding_features": pluker_features,
+        "sample_locs_dict": None,
+        "sample_locs_packed": epipolar_masks_packed(F, w2c.shape[1], H_px, W_px, attention_resolution),
+        "cond_frame_index": cond_frame_index,
+        "add_type": add_type,
+        "fundamental": F,
+        "relative_c2w": rel,
+    }
+
+
+def synthetic_trajectory(b, t, device, yaw_step=0.02, dx=0.05, dz=0.02):
+    """Benchmark camera of SURVEY.md section 8(d): yaw 0.02 rad/frame + translation (0.05, 0, 0.02)/frame.
+    Returns w2c [b,t,4,4]."""
+    f = torch.arange(t, dtype=torch.float32)
+    c2w = torch.eye(4).repeat(t, 1, 1)
+    c2w[:, 0, 0], c2w[:, 0, 2] = torch.cos(yaw_step * f), torch.sin(yaw_step * f)
+    c2w[:, 2, 0], c2w[:, 2, 2] = -torch.sin(yaw_step * f), torch.cos(yaw_step * f)
+    c2w[:, 0, 3], c2w[:, 2, 3] = dx * f, dz * f
+    return torch.linalg.inv(c2w).unsqueeze(0).repeat(b, 1, 1, 1).to(device)

@@ -1,0 +1,90 @@
+"""Model wrappers behind the reference's ``target:`` paths (``model.camcontexti2v.CamContextI2V``,
+``model.dynamicrafter.DynamiCrafter``, ``baseline.cami2v.cami2v.CamI2V``): the sampling-side slice.
+
+They accept the yaml ``params`` of configs/models/camcontexti2v_256.yaml / configs/baseline/*.yaml,
+build the MI355X UNet through ``unet_config``, add the camera modules natively (the reference
+monkey-patches them in, model/camcontexti2v.py:111-170) and expose ``apply_model`` / ``sample_log`` /
+``camera_condition``.  The once-per-clip feeders that need third-party weights or are ranked "next"
+in SURVEY.md section 8f (VAE, OpenCLIP, Resampler, pose encoder, latent adaptor) are not instantiated:
+their configs are kept on the object and their outputs (c_concat, c_crossattn, Pluecker features) are
+inputs of the hot path.
+"""
+from . import camera
+from .diffusion import LatentDiffusionCore
+
+_FEEDER_KEYS = ("first_stage_config", "cond_stage_config", "img_cond_stage_config", "image_proj_stage_config",
+                "pose_encoder_config", "multi_latent_adaptor", "pose_guided_cond_encoder_config")
+
+
+class DynamiCrafter(LatentDiffusionCore):
+    """Image-to-video base model (reference model/dynamicrafter.py, lvdm/models/ddpm3d.py:1030-1248)."""
+
+    def __init__(self, unet_config, *args, **kwargs):
+        self.feeder_configs = {k: kwargs.pop(k) for k in _FEEDER_KEYS if k in kwargs}
+        self.uncond_type = kwargs.pop("uncond_type", "empty_seq")
+        self.scale_factor = kwargs.pop("scale_factor", 1.0)
+        kwargs.setdefault("conditioning_key", "hybrid")
+        image_size = kwargs.pop("image_size", [32, 32])
+        super().__init__(unet_config, *args, image_size=image_size, **kwargs)
+
+
+class CameraControlLVDM(DynamiCrafter):
+    """Adds camera conditioning to the UNet (reference model/base.py:20-70)."""
+
+    def __init__(self, *args, add_type="add_into_temporal_attn", epipolar_config=None, normalize_T0=False,
+                 camera_embedding="plucker", **kwargs):
+        pose_cfg = kwargs.get("pose_encoder_config")
+        super().__init__(*args, **kwargs)
+        self.add_type = add_type
+        self.normalize_T0 = normalize_T0
+        self.camera_embedding = camera_embedding
+        self.epipolar_config = dict(epipolar_config) if epipolar_config is not None else None
+        unet = self.model.diffusion_model
+        if self.epipolar_config is not None or pose_cfg is not None:
+            epi = None
+            if self.epipolar_config is not None:
+                epi = {k: v for k, v in self.epipolar_config.items()
+                       if k in ("origin_h", "origin_w", "is_3d_full_attn", "num_register_tokens",
+                                "compression_factor", "attention_resolution", "only_on_cond_frame")}
+                unet.epipolar_origin_h = epi.get("origin_h", 256)
+            unet.enable_camera_conditioning(epi, pluker=pose_cfg is not None)
+
+    def camera_condition(self, K, w2c, cond_frame_index, H_px, W_px, pluker_features=None,
+                         trace_scale_factor=1.0, generator=None, noise=None):
+        """Geometry half of get_batch_input_camera_condition_process (model/camcontexti2v.py:525-572)."""
+        cfg = self.epipolar_config or {}
+        if self.epipolar_config is None or cfg.get("is_3d_full_attn", False):
+            return {"pluker_embedding_features": pluker_features, "sample_locs_dict": None,
+                    "cond_frame_index": cond_frame_index, "add_type": self.add_type}
+        return camera.camera_condition(
+            K, w2c, cond_frame_index, H_px, W_px, pluker_features, self.add_type,
+            attention_resolution=cfg.get("attention_resolution", [8, 4, 2, 1]), trace_scale_factor=trace_scale_factor,
+            perturb=cfg.get("add_small_perturbation_on_zero_T", False), generator=generator, noise=noise)
+
+
+class CamContextI2V(CameraControlLVDM):
+    """CamContextI2V (reference model/camcontexti2v.py:30-170): camera-conditioned UNet + context frames.
+    The context-frame adaptor only changes the *inputs* (c_concat, c_crossattn length); the UNet is the
+    same as CamI2V's."""
+
+    def __init__(self, *args, multi_cond_strategy=None, use_zero_conv_latent_input=False, **kwargs):
+        for k in ("plucker_proj_trainable", "epipolar_attn_trainable", "pose_guided_cond_trainable",
+                  "multi_cond_adaptor_trainable", "first_unet_block_trainable", "first_unet_block_freeze_steps",
+                  "use_cross_normalization", "use_semantic_branch", "epipolar_mask_freeze_steps",
+                  "cross_normalization_mode", "use_pose_embedding_in_latent_adaptor", "inject_trainable_lora_unet",
+                  "lora_config", "diffusion_model_trainable_param_list", "pose_encoder_trainable",
+                  "cond_stage_trainable", "image_proj_model_trainable", "weight_decay"):
+            kwargs.pop(k, None)
+        super().__init__(*args, **kwargs)
+        self.multi_cond_strategy = multi_cond_strategy
+        self.use_zero_conv_latent_input = use_zero_conv_latent_input
+
+
+class CamI2V(CameraControlLVDM):
+    """CamI2V baseline (reference baseline/cami2v/cami2v.py): same camera-conditioned UNet, no context frames."""
+
+    def __init__(self, *args, **kwargs):
+        for k in ("diffusion_model_trainable_param_list", "pose_encoder_trainable", "cond_stage_trainable",
+                  "image_proj_model_trainable", "weight_decay"):
+            kwargs.pop(k, None)
+        super().__init__(*args, **kwargs)

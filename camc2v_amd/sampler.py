@@ -119,7 +119,7 @@ class DDIMSampler(object):
                       quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100,
                       temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1.0, unconditional_conditioning=None, verbose=True, precision=None,
-                      fs=None, guidance_rescale=0.0, injected_noise=None, **kwargs):
+                      fs=None, guidance_rescale=0.0, injected_noise=None, use_graph=False, **kwargs):
         """``injected_noise``: optional sequence of per-step N(0,1) tensors used instead of torch.randn
         (parity tests; the reference draws with noise_like, lvdm/common.py:31-34)."""
         if ddim_use_original_steps or timesteps is not None:
