@@ -18,6 +18,51 @@ namespace {
 
 constexpr int BK = 64;  // bf16 elements per K slab = 128 bytes per LDS row
 
+// epilogue for 4 consecutive output columns n..n+3 of row m (acc already holds the full K sum)
+__device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] *= p.alpha;
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+    }
+    if (p.bias2) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + (long)(m / p.rows_per_batch) * p.ldb2 + n);
+        o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+    }
+    if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r]);
+    } else if (p.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r]);
+    }
+    if (p.residual) {
+        const float4 rv = *reinterpret_cast<const float4*>(p.residual + (long)m * p.ldr + n);
+        o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+    if (p.out_f32) {
+        *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+    }
+}
+
+// GEGLU: value columns n..n+3 and gate columns n+16..n+19 of the interleaved weight layout
+__device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, const float a_[4], const float g_[4]) {
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = a_[r] * p.alpha, g = g_[r] * p.alpha;
+        if (p.bias) { a += p.bias[n + r]; g += p.bias[n + 16 + r]; }
+        o[r] = a * gelu_erf_f(g);
+    }
+    const int nc = (n >> 5) * 16 + (n & 15);
+    uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = pk;
+}
+
 template <int MT, int NT, bool A_F32, int GATHER>
 __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
@@ -39,6 +84,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int split = (p.split_k > 1) ? bid % p.split_k : 0;
+    if (p.split_k > 1) bid /= p.split_k;
     const int m0 = (bid / tiles_n) * BM;
     const int n0 = (bid % tiles_n) * BN;
 
@@ -66,8 +113,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
         }
     }
     const int slabs_per_tap = p.K / BK;
-    const int nslab = p.taps * slabs_per_tap;
+    const int nslab_all = p.taps * slabs_per_tap;
     const int ldw = p.taps * p.K;
+    // split-K: this workgroup sums slabs [s_begin, s_end) and leaves the epilogue to the reduce kernel
+    const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
+    const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
 
     uint4 ra[AR];            // bf16 path
     float4 rf[A_F32 ? 2 * AR : 1];  // fp32 path (converted when written to LDS)
@@ -152,13 +202,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
     const int fr = lane & 15;  // fragment row (m for activations, n for weights)
     const int fg = lane >> 4;  // k group: 8 consecutive k at 8*fg
 
-    load_slab(0);
+    load_slab(s_begin);
     store_slab(0);
     __syncthreads();
 
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) load_slab(s + 1);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_slab(s + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + fg;
@@ -180,32 +230,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
                     // weights as the MFMA A operand (rows = n), activations as B (cols = m)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < nslab) store_slab(buf ^ 1);
+        if (s + 1 < s_end) store_slab(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+fr, n = ..+4*fg ---------------------
-    const int ldc = p.ldc;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = m0 + wm * 16 * MT + 16 * i + fr;
         if (m >= p.M) continue;
-        const float* b2 = p.bias2 ? p.bias2 + (long)(m / p.rows_per_batch) * p.ldb2 : nullptr;
+        if (p.split_k > 1) {  // raw partial sums -> workspace [split][M][N]
+            float* wsp = static_cast<float*>(p.ws) + ((long)split * p.M + m) * p.N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+                if (n < p.N) *reinterpret_cast<float4*>(wsp + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            continue;
+        }
         if (p.geglu) {
 #pragma unroll
             for (int j = 0; j < NT; j += 2) {
                 const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;  // value columns; gate at n + 16
                 if (n >= p.N) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = acc[i][j][r] * p.alpha, g = acc[i][j + 1][r] * p.alpha;
-                    if (p.bias) { a += p.bias[n + r]; g += p.bias[n + 16 + r]; }
-                    o[r] = a * gelu_erf_f(g);
-                }
-                const int nc = (n0 + wn * 16 * NT + 16 * j) / 2 + 4 * fg;
-                uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * ldc + nc) = pk;
+                const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                epilogue_geglu(p, m, n, a_, g_);
             }
             continue;
         }
@@ -213,34 +263,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
         for (int j = 0; j < NT; ++j) {
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
             if (n >= p.N) continue;
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r] * p.alpha;
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+            float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store(p, m, n, o);
+        }
+    }
+}
+
+// split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const CcvGemm p) {
+    const int n4 = p.N >> 2;
+    const long total = (long)p.M * n4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        if (p.geglu && (n & 16)) continue;  // gate columns are consumed together with their value columns
+        auto sum = [&](int col, float o[4]) {
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+            for (int sp = 0; sp < p.split_k; ++sp) {
+                const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(p.ws) + ((long)sp * p.M + m) * p.N + col);
+                o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
             }
-            if (b2) {
-                const float4 bv = *reinterpret_cast<const float4*>(b2 + n);
-                o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-            }
-            if (p.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r]);
-            } else if (p.act == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r]);
-            }
-            if (p.residual) {
-                const float4 rv = *reinterpret_cast<const float4*>(p.residual + (long)m * p.ldr + n);
-                o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
-            }
-            if (p.out_f32) {
-                *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-                uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * ldc + n) = pk;
-            }
+        };
+        float o[4];
+        sum(n, o);
+        if (p.geglu) {
+            float g[4];
+            sum(n + 16, g);
+            epilogue_geglu(p, m, n, o, g);
+        } else {
+            epilogue_store(p, m, n, o);
         }
     }
 }
@@ -248,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
 template <int MT, int NT, bool A_F32, int GATHER>
 int launch(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
     const size_t lds = 2 * (BM + BN) * 128;
     auto kern = gemm_kernel<MT, NT, A_F32, GATHER>;
     static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
@@ -258,7 +308,39 @@ int launch(const CcvGemm& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
     CCV_LAUNCH_CHECK("ccv_gemm");
+    if (p.split_k > 1) {
+        const long total = (long)p.M * (p.N / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
+    }
     return CCV_OK;
+}
+
+// Tile shape for a problem: the largest tile that still yields >= ~1 workgroup per CU (256 CUs).
+inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
+    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if (p.N % 128 == 0 && tiles(128, 128) >= 256) { mt = 4; nt = 4; return; }
+    if (p.N % 128 == 0 && tiles(64, 128) >= 256) { mt = 2; nt = 4; return; }
+    if (p.N % 64 == 0 && tiles(128, 64) >= 320) { mt = 4; nt = 2; return; }
+    mt = 2; nt = 2;
+}
+
+// Split-K factor: long-K problems that cannot fill the chip with output tiles alone (the 4x4 / 8x8
+// latent layers stream 30-60 MB of weights through a few dozen workgroups otherwise).
+inline int choose_split(const CcvGemm& p) {
+    int mt, nt;
+    choose_tile(p, mt, nt);
+    const long tiles = (long)((p.M + 32 * mt - 1) / (32 * mt)) * ((p.N + 32 * nt - 1) / (32 * nt));
+    const int nslab = p.taps * (p.K / BK);
+    // measured on MI355X: splitting pays when the grid is at most ~1 workgroup per CU, or up to ~2 per CU
+    // when K is very long (conv3x3 at 8x8 / 4x4 latents: 180-360 slabs); otherwise the reduce pass costs more
+    if (nslab < 16 || tiles >= 512 || (tiles > 256 && nslab < 64)) return 1;
+    long s = (1024 + tiles - 1) / tiles;
+    if (s > nslab / 8) s = nslab / 8;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
 }
 
 template <bool A_F32, int GATHER>
@@ -274,9 +356,19 @@ int dispatch_tile(const CcvGemm& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int64_t ccv_gemm_ws_bytes(const CcvGemm* pp) {
+    if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0 || pp->K % BK != 0 || pp->taps <= 0) return 0;
+    const int s = choose_split(*pp);
+    return s > 1 ? (int64_t)s * pp->M * pp->N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_gemm: null params");
-    const CcvGemm& p = *pp;
+    CcvGemm p = *pp;
+    {   // split-K only when the caller provided the workspace ccv_gemm_ws_bytes() asks for
+        const int s = (p.K > 0 && p.K % BK == 0 && p.M > 0 && p.N > 0 && p.taps > 0) ? choose_split(p) : 1;
+        p.split_k = (s > 1 && p.ws != nullptr && p.ws_bytes >= (int64_t)s * p.M * p.N * (int64_t)sizeof(float)) ? s : 1;
+    }
     CCV_REQUIRE(p.A && p.W && p.C, CCV_EINVAL, "ccv_gemm: null A/W/C");
     CCV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, CCV_EINVAL, "ccv_gemm: non-positive M/N/K (%d,%d,%d)", p.M, p.N, p.K);
     CCV_REQUIRE(p.K % BK == 0, CCV_ESHAPE, "ccv_gemm: K=%d must be a multiple of 64", p.K);

@@ -3,127 +3,141 @@
 // Both are HBM/L2-bound streaming passes: reads are fully coalesced along the channel axis
 // (a row of C channels is contiguous), statistics are fp32.
 //
-// GroupNorm runs as three launches so that it is deterministic and needs no atomics:
+// GroupNorm runs as three launches (no global atomics, fixed summation tree => deterministic):
 //   gn_stats    grid (chunks, instances): per-chunk per-group (sum, sumsq) partials
 //   gn_finalize grid (instances): partials -> (mean, rstd) per group
 //   gn_apply    grid (chunks, instances): y = (x - mean) * rstd * gamma + beta [, SiLU] -> bf16
-// A thread owns fixed channel PAIRS (pair index t, t+256, ...) for every row of its chunk, so
-// its partial sums belong to fixed groups (channels-per-group is even for every layer here).
+// Every load is a 16-byte (4-channel) access; all reductions run in a fixed order, so the result is
+// bitwise reproducible (channels-per-group is even for every layer here, so a channel pair never
+// straddles two groups).
 #include "ccv_common.h"
 
 namespace {
 
 constexpr int GN_GROUPS = 32;
 constexpr int GN_MAX_CHUNKS = 256;
-constexpr int GN_SLOTS = 8;  // C/2 <= 256 * 8  =>  C <= 4096
 
-__host__ __device__ inline int gn_chunks(int rows) {
-    int c = (rows + 31) / 32;
-    return c < 1 ? 1 : (c > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : c);
+// chunks per instance: aim at ~1024 workgroups in total, at least ~8 rows per chunk
+inline int gn_chunks(int instances, int rows) {
+    int c = (1024 + instances - 1) / instances;
+    const int by_rows = (rows + 7) / 8;
+    if (c > by_rows) c = by_rows;
+    if (c > GN_MAX_CHUNKS) c = GN_MAX_CHUNKS;
+    return c < 1 ? 1 : c;
+}
+// threads per block: a multiple of C/4 (each thread owns 4 fixed channels), <= 1024, ~256 when possible
+inline int gn_threads(int C) {
+    const int cols = C / 4;
+    int r = 256 / cols;
+    if (r < 1) r = 1;
+    return cols * r;
 }
 
 template <bool X_F32>
-__device__ __forceinline__ float2 load_pair(const void* x, long idx_pair) {
-    if (X_F32) return reinterpret_cast<const float2*>(x)[idx_pair];
-    const uint32_t u = reinterpret_cast<const uint32_t*>(x)[idx_pair];
-    return make_float2(bf16_to_f32((uint16_t)(u & 0xffffu)), bf16_to_f32((uint16_t)(u >> 16)));
+__device__ __forceinline__ float4 load4(const void* x, long idx4) {
+    if (X_F32) return reinterpret_cast<const float4*>(x)[idx4];
+    const uint2 u = reinterpret_cast<const uint2*>(x)[idx4];
+    return make_float4(bf16_to_f32((uint16_t)(u.x & 0xffffu)), bf16_to_f32((uint16_t)(u.x >> 16)),
+                       bf16_to_f32((uint16_t)(u.y & 0xffffu)), bf16_to_f32((uint16_t)(u.y >> 16)));
 }
+
+// grid (nchunk, instances), 256 threads.  A wave reads 64 consecutive float4 columns of one row (1 KiB,
+// coalesced); the 4 waves take every 4th row of the chunk.  A lane's columns are fixed (lane + 64*cb), so
+// its partial sums belong to fixed channel pairs; the block then reduces across waves and across the
+// pairs of each group in a FIXED order (no atomics: results are bitwise reproducible).
+constexpr int GN_MAXCB = 16;  // C/4 <= 64 * 16  =>  C <= 4096
 
 template <bool X_F32>
 __global__ __launch_bounds__(256) void gn_stats(const void* x, float* partial, int rows_per_instance, int C) {
-    __shared__ float s_sum[256 * GN_SLOTS], s_sq[256 * GN_SLOTS];
+    extern __shared__ __attribute__((aligned(16))) float gsm[];  // [4 waves][cols][4] then [cols*4]
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int pairs = C >> 1;
+    const int cols = C >> 2;
+    const int ncb = (cols + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows_per_chunk = (rows_per_instance + nchunk - 1) / nchunk;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(rows_per_instance, r0 + rows_per_chunk);
-    float sum[GN_SLOTS], sq[GN_SLOTS];
+    float acc[GN_MAXCB][4];
 #pragma unroll
-    for (int k = 0; k < GN_SLOTS; ++k) sum[k] = sq[k] = 0.f;
-    const long base = (long)inst * rows_per_instance * pairs;
-    for (int r = r0; r < r1; ++r) {
+    for (int cb = 0; cb < GN_MAXCB; ++cb) acc[cb][0] = acc[cb][1] = acc[cb][2] = acc[cb][3] = 0.f;
+    const long base = (long)inst * rows_per_instance * cols;
+    for (int r = r0 + wave; r < r1; r += 4) {
 #pragma unroll
-        for (int k = 0; k < GN_SLOTS; ++k) {
-            const int pi = threadIdx.x + 256 * k;
-            if (pi < pairs) {
-                const float2 v = load_pair<X_F32>(x, base + (long)r * pairs + pi);
-                sum[k] += v.x + v.y;
-                sq[k] += v.x * v.x + v.y * v.y;
+        for (int cb = 0; cb < GN_MAXCB; ++cb) {
+            const int col = lane + 64 * cb;
+            if (cb < ncb && col < cols) {
+                const float4 v = load4<X_F32>(x, base + (long)r * cols + col);
+                acc[cb][0] += v.x + v.y; acc[cb][1] += v.x * v.x + v.y * v.y;
+                acc[cb][2] += v.z + v.w; acc[cb][3] += v.z * v.z + v.w * v.w;
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < GN_SLOTS; ++k) {
-        s_sum[threadIdx.x + 256 * k] = sum[k];
-        s_sq[threadIdx.x + 256 * k] = sq[k];
+    for (int cb = 0; cb < GN_MAXCB; ++cb) {
+        const int col = lane + 64 * cb;
+        if (cb < ncb && col < cols)
+            *reinterpret_cast<float4*>(gsm + ((long)wave * cols + col) * 4) = make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]);
     }
     __syncthreads();
-    if (threadIdx.x < GN_GROUPS) {
-        const int ppg = pairs / GN_GROUPS;  // pairs per group
-        float a = 0.f, b = 0.f;
-        for (int i = 0; i < ppg; ++i) {
-            a += s_sum[threadIdx.x * ppg + i];
-            b += s_sq[threadIdx.x * ppg + i];
-        }
-        float* o = partial + (((long)inst * nchunk + chunk) * GN_GROUPS + threadIdx.x) * 2;
-        o[0] = a;
-        o[1] = b;
+    float* flat = gsm + 4 * cols * 4;  // [pairs][2] = (sum, sumsq) per channel pair
+    for (int i = threadIdx.x; i < cols * 4; i += 256)
+        flat[i] = (gsm[i] + gsm[cols * 4 + i]) + (gsm[2 * cols * 4 + i] + gsm[3 * cols * 4 + i]);
+    __syncthreads();
+    if (threadIdx.x < GN_GROUPS * 2) {
+        const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+        const int ppg = (C / GN_GROUPS) >> 1;  // channel pairs per group (channels per group is even)
+        float a = 0.f;
+        for (int i = 0; i < ppg; ++i) a += flat[(g * ppg + i) * 2 + k];
+        partial[((long)inst * nchunk + chunk) * GN_GROUPS * 2 + threadIdx.x] = a;
     }
 }
 
-__global__ void gn_finalize(const float* partial, float* stats, int nchunk, float inv_count, float eps) {
-    const int inst = blockIdx.x, g = threadIdx.x;
-    if (g >= GN_GROUPS) return;
+// grid (instances), 256 threads: 8 threads per group sum the chunk partials
+__global__ __launch_bounds__(256) void gn_finalize(const float* partial, float* stats, int nchunk, float inv_count, float eps) {
+    const int inst = blockIdx.x, g = threadIdx.x >> 3, j = threadIdx.x & 7;
     float a = 0.f, b = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = j; c < nchunk; c += 8) {
         const float* pp = partial + (((long)inst * nchunk + c) * GN_GROUPS + g) * 2;
         a += pp[0];
         b += pp[1];
     }
-    const float mean = a * inv_count;
-    const float var = fmaxf(b * inv_count - mean * mean, 0.f);
-    stats[((long)inst * GN_GROUPS + g) * 2] = mean;
-    stats[((long)inst * GN_GROUPS + g) * 2 + 1] = rsqrtf(var + eps);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (j == 0) {
+        const float mean = a * inv_count;
+        const float var = fmaxf(b * inv_count - mean * mean, 0.f);
+        stats[((long)inst * GN_GROUPS + g) * 2] = mean;
+        stats[((long)inst * GN_GROUPS + g) * 2 + 1] = rsqrtf(var + eps);
+    }
 }
 
 template <bool X_F32>
-__global__ __launch_bounds__(256) void gn_apply(const void* x, uint16_t* y, const float* gamma, const float* beta,
-                                                const float* stats, int rows_per_instance, int C, int silu) {
+__global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, const float* gamma, const float* beta,
+                                                 const float* stats, int rows_per_instance, int C, int silu) {
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int pairs = C >> 1;
-    const int ppg = pairs / GN_GROUPS;
+    const int cols = C >> 2;
+    const int col = threadIdx.x % cols, roff = threadIdx.x / cols, R = blockDim.x / cols;
     const int rows_per_chunk = (rows_per_instance + nchunk - 1) / nchunk;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(rows_per_instance, r0 + rows_per_chunk);
-    float sc0[GN_SLOTS], sc1[GN_SLOTS], sh0[GN_SLOTS], sh1[GN_SLOTS];
+    const int cpg = C / GN_GROUPS;
+    float sc[4], sh[4];
 #pragma unroll
-    for (int k = 0; k < GN_SLOTS; ++k) {
-        const int pi = threadIdx.x + 256 * k;
-        sc0[k] = sc1[k] = sh0[k] = sh1[k] = 0.f;
-        if (pi < pairs) {
-            const int g = pi / ppg;
-            const float mean = stats[((long)inst * GN_GROUPS + g) * 2];
-            const float rstd = stats[((long)inst * GN_GROUPS + g) * 2 + 1];
-            sc0[k] = rstd * gamma[2 * pi];
-            sc1[k] = rstd * gamma[2 * pi + 1];
-            sh0[k] = beta[2 * pi] - mean * sc0[k];
-            sh1[k] = beta[2 * pi + 1] - mean * sc1[k];
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * col + k, g = c / cpg;
+        const float mean = stats[((long)inst * GN_GROUPS + g) * 2];
+        const float rstd = stats[((long)inst * GN_GROUPS + g) * 2 + 1];
+        sc[k] = rstd * gamma[c];
+        sh[k] = beta[c] - mean * sc[k];
     }
-    const long base = (long)inst * rows_per_instance * pairs;
-    uint32_t* yo = reinterpret_cast<uint32_t*>(y);
-    for (int r = r0; r < r1; ++r) {
-#pragma unroll
-        for (int k = 0; k < GN_SLOTS; ++k) {
-            const int pi = threadIdx.x + 256 * k;
-            if (pi < pairs) {
-                const long idx = base + (long)r * pairs + pi;
-                const float2 v = load_pair<X_F32>(x, idx);
-                float a = v.x * sc0[k] + sh0[k], b = v.y * sc1[k] + sh1[k];
-                if (silu) { a = silu_f(a); b = silu_f(b); }
-                yo[idx] = pack_bf16x2(a, b);
-            }
-        }
+    const long base = (long)inst * rows_per_instance * cols;
+    uint2* yo = reinterpret_cast<uint2*>(y);
+    for (int r = r0 + roff; r < r1; r += R) {
+        const long idx = base + (long)r * cols + col;
+        const float4 v = load4<X_F32>(x, idx);
+        float o0 = v.x * sc[0] + sh[0], o1 = v.y * sc[1] + sh[1], o2 = v.z * sc[2] + sh[2], o3 = v.w * sc[3] + sh[3];
+        if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+        yo[idx] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
     }
 }
 
@@ -171,24 +185,26 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     CCV_REQUIRE(x && y && gamma && beta && ws, CCV_EINVAL, "ccv_groupnorm: null pointer");
     CCV_REQUIRE(instances > 0 && rows_per_instance > 0, CCV_EINVAL, "ccv_groupnorm: non-positive sizes");
     CCV_REQUIRE(instances <= 65535, CCV_ESHAPE, "ccv_groupnorm: too many instances");
-    CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 512 * GN_SLOTS, CCV_ESHAPE, "ccv_groupnorm: C=%d must be a multiple of 64 and <= 4096", C);
+    CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm: C=%d must be a multiple of 64 and <= 4096", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nchunk = gn_chunks(rows_per_instance);
+    const int nchunk = gn_chunks(instances, rows_per_instance);
+    const int nthreads = gn_threads(C);
     float* partial = static_cast<float*>(ws);
     float* stats = partial + (long)instances * GN_MAX_CHUNKS * GN_GROUPS * 2;
     dim3 grid(nchunk, instances);
+    const size_t lds = (size_t)(C / 4) * 4 * sizeof(float) * 5;  // 4 per-wave slabs + the reduced row
     if (x_f32)
-        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(256), 0, st, x, partial, rows_per_instance, C);
+        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(256), lds, st, x, partial, rows_per_instance, C);
     else
-        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(256), 0, st, x, partial, rows_per_instance, C);
+        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(256), lds, st, x, partial, rows_per_instance, C);
     CCV_LAUNCH_CHECK("ccv_groupnorm(stats)");
     const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
-    hipLaunchKernelGGL(gn_finalize, dim3(instances), dim3(64), 0, st, partial, stats, nchunk, inv_count, eps);
+    hipLaunchKernelGGL(gn_finalize, dim3(instances), dim3(256), 0, st, partial, stats, nchunk, inv_count, eps);
     CCV_LAUNCH_CHECK("ccv_groupnorm(finalize)");
     if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(256), 0, st, x, y, gamma, beta, stats, rows_per_instance, C, silu);
+        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, stats, rows_per_instance, C, silu);
     else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(256), 0, st, x, y, gamma, beta, stats, rows_per_instance, C, silu);
+        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, stats, rows_per_instance, C, silu);
     CCV_LAUNCH_CHECK("ccv_groupnorm(apply)");
     return CCV_OK;
 }

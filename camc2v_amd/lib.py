@@ -22,6 +22,7 @@ class CcvGemm(C.Structure):
         ("stride", i32), ("upsample", i32), ("frames", i32), ("hw", i32),
         ("rows_per_batch", i32), ("act", i32), ("geglu", i32), ("out_f32", i32),
         ("alpha", f32),
+        ("ws", vp), ("ws_bytes", i64), ("split_k", i32),
     ]
 
 
@@ -50,6 +51,7 @@ SIGNATURES = {
     "ccv_version": (i32, []),
     "ccv_last_error": (C.c_char_p, []),
     "ccv_gemm": (i32, [C.POINTER(CcvGemm), vp]),
+    "ccv_gemm_ws_bytes": (i64, [C.POINTER(CcvGemm)]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
     "ccv_groupnorm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),

@@ -93,6 +93,10 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         p.frames, p.hw = tconv
     p.rows_per_batch = rows_per_batch
     p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), int(out_f32), alpha
+    ws_bytes = lib().ccv_gemm_ws_bytes(C.byref(p))
+    if ws_bytes > 0:  # split-K workspace for long-K / few-tile problems
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+        p.ws, p.ws_bytes = _ptr(ws), ws_bytes
     check(lib().ccv_gemm(C.byref(p), _stream()), "ccv_gemm")
     return out
 

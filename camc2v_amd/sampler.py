@@ -64,6 +64,84 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     return sig.float().numpy(), a.numpy(), a_prev.float().numpy()
 
 
+class _GraphedStep:
+    """One CFG DDIM step (batched UNet forward + fused guidance/update) captured into a hipGraph.
+
+    The ~1.4k kernel launches of a step are replayed with one call; only three tiny device copies
+    (timestep row, coefficient row, noise) precede each replay.  The capture bakes in the device addresses of
+    the conditioning tensors, so graphs are cached on the model keyed by tensor identity and shapes: sampling
+    again with the same conditioning tensors (the benchmark; repeated seeds of one prompt) reuses the graph,
+    new conditioning captures a new one (costs about one extra step)."""
+
+    MAX_CACHED = 2
+
+    @staticmethod
+    def _key(x, cond, stochastic, kw):
+        def ident(o):
+            if torch.is_tensor(o):
+                return ("T", id(o), o.data_ptr(), tuple(o.shape), o._version)
+            if isinstance(o, dict):
+                return tuple((k, ident(v)) for k, v in sorted(o.items(), key=lambda kv: str(kv[0])))
+            if isinstance(o, (list, tuple)):
+                return tuple(ident(v) for v in o)
+            return ("V", repr(o))
+        kw = dict(kw)
+        uc = kw.get("unconditional_conditioning")
+        if isinstance(uc, dict):  # its camera entry is derived from `cond` inside the step (and added in place)
+            kw["unconditional_conditioning"] = {k: v for k, v in uc.items() if k != "camera_condition"}
+        return (tuple(x.shape), stochastic, ident(cond), ident(kw))
+
+    @classmethod
+    def get(cls, sampler, x, cond, stochastic, kw):
+        cache = sampler.model.__dict__.setdefault("_ccv_graph_cache", {})
+        key = cls._key(x, cond, stochastic, kw)
+        hit = cache.get(key)
+        if hit is None:
+            while len(cache) >= cls.MAX_CACHED:
+                cache.pop(next(iter(cache)))
+            hit = cache[key] = cls(sampler, x, cond, stochastic, kw)
+        hit.sampler = sampler
+        return hit
+
+    def __init__(self, sampler, x, cond, stochastic, kw):
+        dev = x.device
+        self.keepalive = (cond, kw)
+        self.x = torch.empty_like(x)
+        self.t = torch.zeros(x.shape[0], dtype=torch.long, device=dev)
+        self.coef = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.noise = torch.zeros_like(x) if stochastic else None
+        self.x.copy_(x)
+        self.coef.copy_(sampler.ddim_coef[0])
+
+        def step():
+            return sampler.p_sample_ddim(self.x, cond, self.t, index=0, noise=self.noise, coef=self.coef, **kw)
+
+        # warm-up on a side stream: packs weights, fills the step-invariant caches, primes the allocator
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.x_prev, self.pred_x0 = step()
+
+    def run(self, x, t_row, coef_row, noise):
+        if x.data_ptr() != self.x_prev.data_ptr():
+            self.x.copy_(x)
+        else:
+            self.x.copy_(self.x_prev)
+        self.t.copy_(t_row)
+        self.coef.copy_(coef_row)
+        if self.noise is not None:
+            if noise is None:
+                self.noise.normal_()
+            else:
+                self.noise.copy_(noise)
+        self.graph.replay()
+        return self.x_prev, self.pred_x0
+
+
 class DDIMSampler(object):
     def __init__(self, model, schedule="linear", **kwargs):
         self.model = model
@@ -139,9 +217,22 @@ class DDIMSampler(object):
         # every timestep tensor is built up front: no host->device traffic inside the loop
         ts_all = torch.from_numpy(np.ascontiguousarray(np.flip(steps))).to(device=device, dtype=torch.long)
         ts_all = ts_all[:, None].expand(total, b).contiguous()
+        step_kw = dict(temperature=temperature, unconditional_guidance_scale=unconditional_guidance_scale,
+                       unconditional_conditioning=unconditional_conditioning, fs=fs, guidance_rescale=guidance_rescale,
+                       **kwargs)
+        graphed = None
+        if use_graph and not (callback or img_callback):
+            stochastic = bool(np.any(self.ddim_sigmas != 0.0))
+            graphed = _GraphedStep.get(self, img, cond, stochastic, step_kw)
         for i in range(total):
             index = total - i - 1
             z = injected_noise[i].to(device).float().contiguous() if injected_noise is not None else None
+            if graphed is not None:
+                img, pred_x0 = graphed.run(img, ts_all[i], self.ddim_coef[index], z)
+                if index % log_every_t == 0 or index == total - 1:
+                    intermediates["x_inter"].append(img.clone())
+                    intermediates["pred_x0"].append(pred_x0.clone())
+                continue
             img, pred_x0 = self.p_sample_ddim(img, cond, ts_all[i], index=index, temperature=temperature,
                                               noise_dropout=noise_dropout, score_corrector=score_corrector,
                                               corrector_kwargs=corrector_kwargs, quantize_denoised=quantize_denoised,
@@ -155,6 +246,8 @@ class DDIMSampler(object):
             if index % log_every_t == 0 or index == total - 1:
                 intermediates["x_inter"].append(img)
                 intermediates["pred_x0"].append(pred_x0)
+        if graphed is not None:
+            img = img.clone()  # detach the result from the graph's static output buffer
         if kwargs.get("paste_cond_frame"):
             idx = cond["c_cond_frame_index"]
             bi = torch.arange(img.shape[0], device=device)
@@ -167,7 +260,9 @@ class DDIMSampler(object):
                       temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1.0, unconditional_conditioning=None, uc_type=None,
                       conditional_guidance_scale_temporal=None, mask=None, x0=None, guidance_rescale=0.0,
-                      noise=None, **kwargs):
+                      noise=None, coef=None, **kwargs):
+        """``coef``: optional device tensor [4] = (a_t, a_prev, sigma_t, sqrt(1-a_t)) overriding the table row of
+        ``index`` (lets a captured hipGraph be replayed for every step)."""
         if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.0:
             raise NotImplementedError("original-step / quantised / corrected / dropout sampling is not on the hot path")
         if getattr(self.model, "parameterization", "eps") != "eps":
@@ -192,13 +287,14 @@ class DDIMSampler(object):
             else:
                 e_c = self.model.apply_model(x, t, c, **kwargs)
                 e_uc = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
-        if noise is None and float(self.ddim_sigmas[index]) != 0.0:
+        if noise is None and coef is None and float(self.ddim_sigmas[index]) != 0.0:
             shape = (1, *x.shape[1:]) if repeat_noise else x.shape
             noise = torch.randn(shape, device=x.device).expand(x.shape).contiguous()
         if noise is not None and temperature != 1.0:
             noise = noise * temperature
         x_prev, pred_x0 = ops.ddim_cfg_step(x, e_c.float().contiguous(), None if e_uc is None else e_uc.float().contiguous(),
-                                            noise, self.ddim_coef[index], unconditional_guidance_scale, guidance_rescale)
+                                            noise, coef if coef is not None else self.ddim_coef[index],
+                                            unconditional_guidance_scale, guidance_rescale)
         if kwargs.get("paste_cond_frame"):
             raise NotImplementedError("paste_cond_frame inside the step is not on the generation path")
         return x_prev, pred_x0

@@ -87,7 +87,14 @@ typedef struct CcvGemm {
     int32_t geglu;          /* 0/1 */
     int32_t out_f32;        /* 0: C is bf16, 1: C is fp32 */
     float alpha;
+    void* ws;               /* optional split-K workspace (ccv_gemm_ws_bytes) or NULL */
+    int64_t ws_bytes;
+    int32_t split_k;        /* set by the library; callers leave it 0 */
 } CcvGemm;
+/* Workspace the library would like for this problem (0 = none).  Long-K, few-tile problems (the 4x4 and 8x8
+ * latent layers) are split along K over extra workgroups when the workspace is provided; without it the
+ * call still succeeds, unsplit. */
+int64_t ccv_gemm_ws_bytes(const CcvGemm* p);
 int ccv_gemm(const CcvGemm* p, void* stream);
 
 /* ------------------------------------------------------------------------------------

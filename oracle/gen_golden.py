@@ -25,9 +25,22 @@ import torch.nn as nn
 
 REF = "/root/reference/CamContextI2V"
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE))
 
-from oracle.golden_inputs import SMALL_CFG, FULL_CFG, SEED, small_inputs, checksum  # noqa: E402
+
+def _load_sibling(name):
+    """Import oracle/<name>.py by file path.  The repo root must NOT be on sys.path here: it holds the
+    product's own ``lvdm`` / ``model`` / ``utils`` packages, which would shadow the reference's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(f"_ccv_oracle_{name}", os.path.join(HERE, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_gi = _load_sibling("golden_inputs")
+SMALL_CFG, MEDIUM_CFG, FULL_CFG, SEED = _gi.SMALL_CFG, _gi.MEDIUM_CFG, _gi.FULL_CFG, _gi.SEED
+small_inputs, medium_inputs, checksum = _gi.small_inputs, _gi.medium_inputs, _gi.checksum
+
 
 
 def _install_shims():
@@ -45,11 +58,13 @@ def _install_shims():
     sys.dont_write_bytecode = True
 
 
-def build_reference_unet(cfg, camera=True, device="cpu"):
+def build_reference_unet(cfg, camera=True, device="cpu", origin=64):
     """Reference UNetModel + the camera patch loop of CamContextI2V.__init__ replayed on it."""
     from lvdm.modules.networks.openaimodel3d import UNetModel
     from model.modules import modified_forwards as mf
     from model.modules.epipolar import Epipolar
+    for m_ in (sys.modules["lvdm.modules.networks.openaimodel3d"], mf):
+        assert m_.__file__.startswith(REF), f"{m_.__name__} was not imported from the reference: {m_.__file__}"
 
     with torch.device(device):
         unet = UNetModel(**cfg)
@@ -69,7 +84,7 @@ def build_reference_unet(cfg, camera=True, device="cpu"):
                         m._forward = mf.new__forward_for_BasicTransformerBlock_of_TemporalTransformer.__get__(m, m.__class__)
                         m.add_module("pluker_projection", nn.Linear(dim, dim))
                         m.add_module("epipolar", Epipolar(
-                            query_dim=dim, context_dim=dim, heads=m.attn1.heads, origin_h=64, origin_w=64,
+                            query_dim=dim, context_dim=dim, heads=m.attn1.heads, origin_h=origin, origin_w=origin,
                             is_3d_full_attn=False, num_register_tokens=4,
                             attention_resolution=[8, 4, 2, 1], compression_factor=1))
     return unet.eval()
@@ -112,8 +127,12 @@ def main():
     torch.manual_seed(SEED)
     torch.set_grad_enabled(False)
 
-    from oracle.unet_oracle import seeded_state_dict
-    from oracle.geometry_oracle import synthetic_trajectory
+    seeded_state_dict = _load_sibling("unet_oracle").seeded_state_dict
+    _geo = _load_sibling("geometry_oracle")
+    synthetic_trajectory = _geo.synthetic_trajectory
+    repo_root = os.path.dirname(HERE)
+    assert all(os.path.abspath(p or os.getcwd()) != repo_root for p in sys.path), \
+        "run as `python oracle/gen_golden.py`: the repo root on sys.path would shadow the reference's packages"
 
     # ---- (6) full-config key -> shape manifest (meta device, nothing allocated) --------
     full = build_reference_unet(FULL_CFG, camera=True, device="meta")
@@ -278,6 +297,31 @@ def main():
     res["traj_x0"] = samples.numpy()
     assert "camera_condition" in uncond and uncond["camera_condition"]["is_uc"] is True
     np.savez_compressed(os.path.join(args.out, "unet_small.npz"), **res)
+    del unet
+
+    # ---- (5b) medium-width UNet (model_channels 128, 16x16 latents): tight-tolerance parity fixture -------
+    epipolar_mask = _geo.epipolar_mask
+    unet = build_reference_unet(MEDIUM_CFG, camera=True, origin=128)
+    man = manifest_of(unet)
+    with open(os.path.join(args.out, "unet_medium_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    unet.load_state_dict(seeded_state_dict(man, SEED), strict=True)
+    inp = medium_inputs()
+    K128 = torch.tensor([[64.0, 0, 64], [0, 64.0, 64], [0, 0, 1.0]]).repeat(1, 16, 1, 1)
+    _, F128, masks128 = geometry_via_reference(K128, w2c, cond_idx, 128, 128, pnoise)
+    for d, m in masks128.items():   # the committed fixture carries F only; the oracle rebuilds the masks bit-exactly
+        assert torch.equal(m, epipolar_mask(F128, 128 // d, 128 // d, d)), d
+    cam = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks128,
+               cond_frame_index=torch.zeros(1, dtype=torch.long), add_type="add_to_main_branch")
+    med = dict(F128=F128.numpy(), x=inp["x"].numpy(), t=inp["t"].numpy(), fs=inp["fs"].numpy(),
+               ctx_pf_checksum=np.array(checksum(inp["ctx_pf"])), ctx_rep_checksum=np.array(checksum(inp["ctx_rep"])),
+               mask_popcount=np.array([int(masks128[d].sum()) for d in (8, 16, 32, 64)]))
+    med["y_cam_rep"] = unet(inp["x"], inp["t"], context=inp["ctx_rep"], fs=inp["fs"], camera_condition=cam).numpy()
+    med["y_cam_pf"] = unet(inp["x"], inp["t"], context=inp["ctx_pf"], fs=inp["fs"], camera_condition=cam).numpy()
+    med["y_nocam_pf"] = unet(inp["x"], inp["t"], context=inp["ctx_pf"], fs=inp["fs"], camera_condition=None).numpy()
+    for k in ("y_cam_rep", "y_cam_pf", "y_nocam_pf"):
+        print("medium", k, "absmax", float(np.abs(med[k]).max()), "std", float(med[k].std()))
+    np.savez_compressed(os.path.join(args.out, "unet_medium.npz"), **med)
     print("wrote", args.out, {f: os.path.getsize(os.path.join(args.out, f)) for f in sorted(os.listdir(args.out))})
 
 

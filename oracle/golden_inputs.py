@@ -20,6 +20,13 @@ SMALL_CFG = dict(
 )
 # configs/models/camcontexti2v_256.yaml:40-72
 FULL_CFG = dict(SMALL_CFG, model_channels=320)
+# Better conditioned than SMALL_CFG (whose 1x1 / 2x2 feature maps with 2 channels per GroupNorm group turn
+# the normalisation into a sign function): used for the tight numerical parity checks.
+MEDIUM_CFG = dict(SMALL_CFG, model_channels=128)
+
+
+def medium_inputs():
+    return small_inputs(b=1, T=16, hl=16, seed=SEED + 3, chans=(128, 256, 512, 512))
 
 
 def small_inputs(b=2, T=16, hl=8, seed=SEED + 2, context_dim=1024, chans=(64, 128, 256, 256)):

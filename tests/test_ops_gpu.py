@@ -128,6 +128,36 @@ def test_gemm_tconv3(ops):
     assert_close(out.reshape(b, t, hw, cout).permute(0, 3, 1, 2), ref[..., 0], 2e-3, "tconv3")
 
 
+def test_gemm_split_k_paths(ops):
+    """Few output tiles + long K -> the library splits K over extra workgroups (workspace provided by ops.gemm);
+    every epilogue flavour must survive the two-pass form."""
+    from camc2v_amd.pack import interleave_geglu, pack_conv3x3
+    M, N, K = 512, 1280, 5120
+    a, w = rnd(M, K, seed=70), rnd(N, K, seed=71, scale=0.02)
+    bias = rnd(N, seed=72, dtype=torch.float32)
+    res = rnd(M, N, seed=73, dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    assert_close(ops.gemm(a, w, bias=bias), ref, 1e-2, "split-K bf16 out")
+    stream = res.clone()
+    ops.gemm(a, w, bias=bias, residual=stream, out_f32=True, out=stream)
+    assert_close(stream, ref + res, 2e-3, "split-K in-place residual")
+    assert_close(ops.gemm(a, w, bias=bias, act=ops.ACT_SILU), F.silu(ref), 1e-2, "split-K silu")
+    wg = rnd(2 * 640, K, seed=74, scale=0.02)
+    bg = rnd(2 * 640, seed=75, dtype=torch.float32)
+    wp, bp = interleave_geglu(wg, bg)
+    full = a.float() @ wg.float().t() + bg
+    val, gate = full.chunk(2, dim=-1)
+    assert_close(ops.gemm(a, wp, bias=bp, geglu=True), val * F.gelu(gate), 1.5e-2, "split-K geglu")
+    # 4x4-latent conv: 32 frames x 16 pixels, 1280 -> 1280
+    n, cin, cout, hs = 32, 1280, 1280, 4
+    x = rnd(n, cin, hs, hs, seed=76, dtype=torch.float32).to(torch.bfloat16).float()
+    wt = rnd(cout, cin, 3, 3, seed=77, scale=0.02, dtype=torch.float32).to(torch.bfloat16).float()
+    ref = F.conv2d(x, wt, None, padding=1)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, gather=ops.GATHER_CONV3X3, conv=(hs, hs, hs, hs, 1, 0), out_f32=True)
+    assert_close(out.reshape(n, hs, hs, cout).permute(0, 3, 1, 2), ref, 2e-3, "split-K conv")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from camc2v_amd.lib import CcvError
     with pytest.raises(CcvError):

@@ -96,6 +96,24 @@ def test_unet_default_fs(small):
     _close(y, fx["y_default_fs"])
 
 
+def test_unet_medium_fixture(golden_dir):
+    """model_channels 128, 16x16 latents (well conditioned): the tight-tolerance fixture of the GPU tests."""
+    from oracle.golden_inputs import MEDIUM_CFG, medium_inputs
+    fx = np.load(os.path.join(golden_dir, "unet_medium.npz"))
+    man = json.load(open(os.path.join(golden_dir, "unet_medium_manifest.json")))
+    sd = unet_oracle.seeded_state_dict(man, SEED)
+    inp = medium_inputs()
+    assert checksum(inp["ctx_rep"]) == pytest.approx(float(fx["ctx_rep_checksum"]), abs=1e-6)
+    F = torch.from_numpy(fx["F128"])
+    masks = {d: geometry_oracle.epipolar_mask(F, 128 // d, 128 // d, d) for d in (8, 16, 32, 64)}
+    assert [int(masks[d].sum()) for d in (8, 16, 32, 64)] == list(fx["mask_popcount"])
+    cam = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks, add_type="add_to_main_branch")
+    y = unet_oracle.unet_forward(sd, MEDIUM_CFG, inp["x"], inp["t"], inp["ctx_rep"], inp["fs"], cam, origin_h=128)
+    _close(y, fx["y_cam_rep"])
+    y = unet_oracle.unet_forward(sd, MEDIUM_CFG, inp["x"], inp["t"], inp["ctx_pf"], inp["fs"], None)
+    _close(y, fx["y_nocam_pf"])
+
+
 def test_ddim_tables(golden_dir):
     fx = np.load(os.path.join(golden_dir, "ddim.npz"))
     assert np.allclose(ddim_oracle.alphas_cumprod().astype(np.float32), fx["alphas_cumprod"], rtol=1e-6)
