@@ -12,11 +12,13 @@
 // gather rows per tap), LDS is double buffered and XOR-swizzled so the ds_read_b128
 // fragment reads are bank-conflict free (16-byte chunk c of row r lives at c ^ ((r>>1)&7)).
 // blockIdx is remapped so that the workgroups of one XCD walk neighbouring tiles (L2 reuse).
+#include <stdlib.h>
+
 #include "ccv_common.h"
 
 namespace {
 
-constexpr int BK = 64;  // bf16 elements per K slab = 128 bytes per LDS row
+constexpr int BK = 64;  // K granularity every problem must satisfy (K % 64 == 0)
 
 // epilogue for 4 consecutive output columns n..n+3 of row m (acc already holds the full K sum)
 __device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4]) {
@@ -63,13 +65,30 @@ __device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, c
     *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = pk;
 }
 
-template <int MT, int NT, bool A_F32, int GATHER>
+// BKT = K-slab depth (bf16 elements): 64 -> 128-byte LDS rows, 2 MFMA k-steps per slab, 64 KiB of LDS for a
+// 128x128 tile (2 workgroups per CU); 32 -> 64-byte rows, 1 k-step per slab, 32 KiB (4-5 workgroups per CU:
+// more waves in flight to hide the global-load latency of short-K problems).
+template <int BKT>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    // 16-byte chunk `chunk` of `row`, XOR-swizzled so that the 16 lanes of a ds_read_b128 group hit 16 distinct
+    // 16-byte slots of the 256-byte bank row
+    if (BKT == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    // 64-byte rows: 4 rows per bank row; slot = chunk ^ h(row>>2) with h = (0,2,3,1) keeps every
+    // ds_read_b128 lane group ({0-3,12-15,20-27}, ...) on 16 distinct 16-byte slots
+    return row * 64 + ((chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
+}
+
+template <int MT, int NT, bool A_F32, int GATHER, int BKT>
 __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
-    constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
+    constexpr int CH = BKT / 8;          // 16-byte chunks per LDS row
+    constexpr int RPP = 256 / CH;        // rows staged per pass of the 256 threads
+    constexpr int AR = BM / RPP, BR = BN / RPP;  // rows staged per thread
+    constexpr int ROWB = BKT * 2;        // bytes per LDS row
+    static_assert(AR >= 1 && BR >= 1, "tile too small for this slab depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                 // [2][BM][128 B]
-    unsigned char* sB = smem + 2 * BM * 128;  // [2][BN][128 B]
+    unsigned char* sA = smem;                  // [2][BM][ROWB]
+    unsigned char* sB = smem + 2 * BM * ROWB;  // [2][BN][ROWB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -90,12 +109,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
     const int n0 = (bid % tiles_n) * BN;
 
     // ---- per-thread staging geometry ----------------------------------------------------
-    const int chunk = tid & 7;   // 16-byte chunk (8 bf16) within the 64-wide slab
-    const int srow = tid >> 3;   // 0..31
+    const int chunk = tid % CH;  // 16-byte chunk (8 bf16) within the slab
+    const int srow = tid / CH;   // 0..RPP-1
     int a_base[AR], a_y[AR], a_x[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = m0 + srow + 32 * i;
+        const int m = m0 + srow + RPP * i;
         if (GATHER == 0) {
             a_base[i] = (m < p.M) ? m : -1;
             a_y[i] = a_x[i] = 0;
@@ -112,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
             a_x[i] = 0;
         }
     }
-    const int slabs_per_tap = p.K / BK;
+    const int slabs_per_tap = p.K / BKT;
     const int nslab_all = p.taps * slabs_per_tap;
     const int ldw = p.taps * p.K;
     // split-K: this workgroup sums slabs [s_begin, s_end) and leaves the epilogue to the reduce kernel
@@ -125,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
 
     auto load_slab = [&](int s) {
         const int tap = s / slabs_per_tap;
-        const int kc = (s - tap * slabs_per_tap) * BK + chunk * 8;
+        const int kc = (s - tap * slabs_per_tap) * BKT + chunk * 8;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             long src = -1;
@@ -159,10 +178,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
                     ra[i] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        const int kw = s * BK + chunk * 8;
+        const int kw = s * BKT + chunk * 8;
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int n = n0 + srow + 32 * i;
+            const int n = n0 + srow + RPP * i;
             if (n < p.N)
                 rb[i] = *reinterpret_cast<const uint4*>(p.W + (long)n * ldw + kw);
             else
@@ -173,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
     auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int r = srow + 32 * i;
+            const int r = srow + RPP * i;
             uint4 v;
             if (A_F32) {
                 const float4 lo = rf[2 * i], hi = rf[2 * i + 1];
@@ -184,12 +203,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
             } else {
                 v = ra[i];
             }
-            *reinterpret_cast<uint4*>(sA + (buf * BM + r) * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = v;
+            *reinterpret_cast<uint4*>(sA + buf * BM * ROWB + lds_off<BKT>(r, chunk)) = v;
         }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int r = srow + 32 * i;
-            *reinterpret_cast<uint4*>(sB + (buf * BN + r) * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
+            const int r = srow + RPP * i;
+            *reinterpret_cast<uint4*>(sB + buf * BN * ROWB + lds_off<BKT>(r, chunk)) = rb[i];
         }
     };
 
@@ -210,18 +229,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
         const int buf = (s - s_begin) & 1;
         if (s + 1 < s_end) load_slab(s + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKT / 32; ++ks) {
             const int c = ks * 4 + fg;
             bf16x8 fa[MT], fb[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int r = wm * 16 * MT + 16 * i + fr;
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + (buf * BM + r) * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + buf * BM * ROWB + lds_off<BKT>(r, c));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int r = wn * 16 * NT + 16 * j + fr;
-                fb[j] = *reinterpret_cast<const bf16x8*>(sB + (buf * BN + r) * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                fb[j] = *reinterpret_cast<const bf16x8*>(sB + buf * BN * ROWB + lds_off<BKT>(r, c));
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -269,6 +288,357 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// LDS-DMA variant for bf16 activations: both operand tiles go global -> LDS with global_load_lds_dwordx4
+// (no VGPR staging, no ds_write: on gfx950 a register->LDS store of 16 bytes costs ~13 cycles of the LDS
+// pipe, which made the register-staged loop LDS-bound).  One wave-instruction writes 1 KiB = 8 rows of the
+// 128-byte-row tile linearly (LDS address = wave-uniform base + 16*lane), so the XOR swizzle is applied to
+// the per-lane SOURCE address (lane l fetches logical chunk (l&7) ^ swz(row)) and again on the fragment read.
+// Conv padding / out-of-range rows fetch from a 16-byte zero line.  Two LDS stages: the DMA of slab s+1 is
+// in flight while slab s is multiplied.
+// -------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned char g_zero_line[16];
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int MT, int NT, int GATHER>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions per wave and slab (8 rows each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                 // [2][BM][128 B]
+    unsigned char* sB = smem + 2 * BM * 128;  // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int split = (p.split_k > 1) ? bid % p.split_k : 0;
+    if (p.split_k > 1) bid /= p.split_k;
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    // staging geometry: DMA instruction j of this wave fills tile rows 8*(4j+wave) .. +7
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    int a_base[AI], a_y[AI], a_x[AI], a_col[AI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int r = 8 * (4 * j + wave) + lrow;
+        a_col[j] = (lchunk ^ ((r >> 1) & 7)) * 8;
+        const int m = m0 + r;
+        if (GATHER == 0) {
+            a_base[j] = (m < p.M) ? m : -1;
+            a_y[j] = a_x[j] = 0;
+        } else if (GATHER == 1) {
+            const int pix = p.out_h * p.out_w;
+            const int img = m / pix, rem = m - img * pix;
+            const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+            a_base[j] = (m < p.M) ? img * p.src_h * p.src_w : -1;
+            a_y[j] = oy * p.stride - 1;
+            a_x[j] = ox * p.stride - 1;
+        } else {
+            a_base[j] = (m < p.M) ? m : -1;
+            a_y[j] = (m / p.hw) % p.frames;
+            a_x[j] = 0;
+        }
+    }
+    const int ldw = p.taps * p.K;
+    const uint16_t* b_ptr[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int r = 8 * (4 * j + wave) + lrow;
+        const int n = n0 + r;
+        b_ptr[j] = (n < p.N) ? p.W + (long)n * ldw + (lchunk ^ ((r >> 1) & 7)) * 8 : nullptr;
+    }
+    const int slabs_per_tap = p.K / BK;
+    const int nslab_all = p.taps * slabs_per_tap;
+    const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
+    const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
+
+    auto issue = [&](int s, int buf) {
+        const int tap = s / slabs_per_tap;
+        const int kc = (s - tap * slabs_per_tap) * BK;
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            long src = -1;
+            if (a_base[j] >= 0) {
+                if (GATHER == 0) {
+                    src = a_base[j];
+                } else if (GATHER == 1) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const int iy = a_y[j] + ky, ix = a_x[j] + kx;
+                    const int vh = p.src_h << p.upsample, vw = p.src_w << p.upsample;
+                    if (iy >= 0 && iy < vh && ix >= 0 && ix < vw)
+                        src = a_base[j] + (iy >> p.upsample) * p.src_w + (ix >> p.upsample);
+                } else {
+                    const int f = a_y[j] + tap - 1;
+                    if (f >= 0 && f < p.frames) src = (long)a_base[j] + (long)(tap - 1) * p.hw;
+                }
+            }
+            const uint16_t* g = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sA + (buf * BM + 8 * (4 * j + wave)) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const uint16_t* g = b_ptr[j] ? b_ptr[j] + s * BK : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sB + (buf * BN + 8 * (4 * j + wave)) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+
+    issue(s_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) issue(s + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + fg;
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * 16 * MT + 16 * i + fr;
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + buf * BM * 128 + lds_off<64>(r, c));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * 16 * NT + 16 * j + fr;
+                fb[j] = *reinterpret_cast<const bf16x8*>(sB + buf * BN * 128 + lds_off<64>(r, c));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * 16 * MT + 16 * i + fr;
+        if (m >= p.M) continue;
+        if (p.split_k > 1) {
+            float* wsp = static_cast<float*>(p.ws) + ((long)split * p.M + m) * p.N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+                if (n < p.N) *reinterpret_cast<float4*>(wsp + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            continue;
+        }
+        if (p.geglu) {
+#pragma unroll
+            for (int j = 0; j < NT; j += 2) {
+                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+                if (n >= p.N) continue;
+                const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                epilogue_geglu(p, m, n, a_, g_);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+            if (n >= p.N) continue;
+            float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store(p, m, n, o);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Wide LDS-DMA variant: block tile 128 x 320, wave tile 64 x 160 (2 x 2 waves), 32-deep K slabs in a
+// 4-stage LDS ring (3 slabs of DMA in flight behind counted s_waitcnt vmcnt + raw s_barrier).
+// Why this shape: with 64 x 64 wave tiles the fragment reads alone need 128 B/clk of LDS per workgroup
+// (2 workgroups per CU = the whole 256 B/clk LDS port), so the loop is LDS-read bound at ~25 % of the MFMA
+// peak.  A 64 x 160 wave tile reads (64+160) rows per 40 MFMAs: 22 B/clk per wave.  Every channel count of
+// the model is a multiple of 320, so N tiles exactly and M = 32768 gives 256 workgroups = one per CU.
+// -------------------------------------------------------------------------------------------------
+constexpr int WIDE_BM = 128, WIDE_BN = 320, WIDE_BK = 32, WIDE_ST = 4;
+constexpr int WIDE_STAGE_BYTES = (WIDE_BM + WIDE_BN) * WIDE_BK * 2;  // 28 KiB
+
+template <int GATHER>
+__global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
+    constexpr int MT = 4, NT = 10;
+    constexpr int AI = 2, BI = 5;  // DMA wave-instructions per wave and slab (16 rows of 64 B each)
+    constexpr int PER_SLAB = AI + BI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = p.N / WIDE_BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int split = (p.split_k > 1) ? bid % p.split_k : 0;
+    if (p.split_k > 1) bid /= p.split_k;
+    const int m0 = (bid / tiles_n) * WIDE_BM;
+    const int n0 = (bid % tiles_n) * WIDE_BN;
+
+    const int lrow = lane >> 2, lchunk = lane & 3;
+    int a_base[AI], a_y[AI], a_x[AI], a_col[AI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int r = 16 * (4 * j + wave) + lrow;
+        a_col[j] = (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
+        const int m = m0 + r;
+        if (GATHER == 0) {
+            a_base[j] = (m < p.M) ? m : -1;
+            a_y[j] = a_x[j] = 0;
+        } else if (GATHER == 1) {
+            const int pix = p.out_h * p.out_w;
+            const int img = m / pix, rem = m - img * pix;
+            const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
+            a_base[j] = (m < p.M) ? img * p.src_h * p.src_w : -1;
+            a_y[j] = oy * p.stride - 1;
+            a_x[j] = ox * p.stride - 1;
+        } else {
+            a_base[j] = (m < p.M) ? m : -1;
+            a_y[j] = (m / p.hw) % p.frames;
+            a_x[j] = 0;
+        }
+    }
+    const int ldw = p.taps * p.K;
+    const uint16_t* b_ptr[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int r = 16 * (4 * j + wave) + lrow;
+        b_ptr[j] = p.W + (long)(n0 + r) * ldw + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
+    }
+    const int slabs_per_tap = p.K / WIDE_BK;
+    const int nslab_all = p.taps * slabs_per_tap;
+    const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
+    const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
+
+    auto issue = [&](int s, int stage) {
+        unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
+        unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
+        const int tap = s / slabs_per_tap;
+        const int kc = (s - tap * slabs_per_tap) * WIDE_BK;
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            long src = -1;
+            if (a_base[j] >= 0) {
+                if (GATHER == 0) {
+                    src = a_base[j];
+                } else if (GATHER == 1) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const int iy = a_y[j] + ky, ix = a_x[j] + kx;
+                    const int vh = p.src_h << p.upsample, vw = p.src_w << p.upsample;
+                    if (iy >= 0 && iy < vh && ix >= 0 && ix < vw)
+                        src = a_base[j] + (iy >> p.upsample) * p.src_w + (ix >> p.upsample);
+                } else {
+                    const int f = a_y[j] + tap - 1;
+                    if (f >= 0 && f < p.frames) src = (long)a_base[j] + (long)(tap - 1) * p.hw;
+                }
+            }
+            const uint16_t* g = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sA + 16 * (4 * j + wave) * 64), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(b_ptr[j] + s * WIDE_BK), (lptr_t*)(sB + 16 * (4 * j + wave) * 64), 16, 0, 0);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // prologue: three slabs in flight
+#pragma unroll
+    for (int k = 0; k < WIDE_ST - 1; ++k)
+        if (s_begin + k < s_end) issue(s_begin + k, k);
+
+    for (int s = s_begin; s < s_end; ++s) {
+        const int stage = (s - s_begin) & (WIDE_ST - 1);
+        // slab s must have landed; up to two younger slabs may stay in flight (7 DMA instructions each per wave)
+        const int younger = min(WIDE_ST - 2, s_end - 1 - s);
+        if (younger >= 2)
+            asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
+        else if (younger == 1)
+            asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // the stage consumed in the previous iteration is free now: every wave passed the barrier after reading it
+        if (s + WIDE_ST - 1 < s_end) issue(s + WIDE_ST - 1, (stage + WIDE_ST - 1) & (WIDE_ST - 1));
+        const unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
+        const unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
+        bf16x8 fa[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off<32>(wm * 64 + 16 * i + fr, fg));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sB + lds_off<32>(wn * 160 + 16 * j + fr, fg));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + fr;
+        if (m >= p.M) continue;
+        if (p.split_k > 1) {
+            float* wsp = static_cast<float*>(p.ws) + ((long)split * p.M + m) * p.N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 160 + 16 * j + 4 * fg;
+                *reinterpret_cast<float4*>(wsp + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+            continue;
+        }
+        if (p.geglu) {
+#pragma unroll
+            for (int j = 0; j < NT; j += 2) {
+                const int n = n0 + wn * 160 + 16 * j + 4 * fg;
+                const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                epilogue_geglu(p, m, n, a_, g_);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * 160 + 16 * j + 4 * fg;
+            float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue_store(p, m, n, o);
+        }
+    }
+}
+
 // split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(const CcvGemm p) {
     const int n4 = p.N >> 2;
@@ -295,12 +665,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const CcvGemm p) {
     }
 }
 
-template <int MT, int NT, bool A_F32, int GATHER>
+template <int MT, int NT, bool A_F32, int GATHER, int BKT>
 int launch(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
-    const size_t lds = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<MT, NT, A_F32, GATHER>;
+    const size_t lds = 2 * (BM + BN) * BKT * 2;
+    auto kern = gemm_kernel<MT, NT, A_F32, GATHER, BKT>;
     static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -343,15 +713,95 @@ inline int choose_split(const CcvGemm& p) {
     return s < 2 ? 1 : (int)s;
 }
 
+template <int MT, int NT, int GATHER>
+int launch_dma(const CcvGemm& p, hipStream_t st) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
+    const size_t lds = 2 * (BM + BN) * 128;
+    auto kern = gemm_dma_kernel<MT, NT, GATHER>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm(dma)");
+    if (p.split_k > 1) {
+        const long total = (long)p.M * (p.N / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
+    }
+    return CCV_OK;
+}
+
+template <int GATHER>
+int launch_wide(const CcvGemm& p, hipStream_t st) {
+    const int tiles = ((p.M + WIDE_BM - 1) / WIDE_BM) * (p.N / WIDE_BN) * (p.split_k > 1 ? p.split_k : 1);
+    const size_t lds = (size_t)WIDE_ST * WIDE_STAGE_BYTES;
+    auto kern = gemm_dma_wide_kernel<GATHER>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm(wide)");
+    if (p.split_k > 1) {
+        const long total = (long)p.M * (p.N / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
+    }
+    return CCV_OK;
+}
+
+// the wide tile applies when N tiles exactly by 320 and the grid fills most of the chip
+inline bool wide_applies(const CcvGemm& p) {
+    static const bool enabled = [] { const char* e = getenv("CCV_GEMM_WIDE"); return !(e && e[0] == '0'); }();
+    if (!enabled || p.a_f32 || p.N % WIDE_BN != 0 || p.split_k > 1) return false;
+    const long tiles = (long)((p.M + WIDE_BM - 1) / WIDE_BM) * (p.N / WIDE_BN);
+    // measured on MI355X: wins on long-K problems (conv3x3 at 32x32 latents: 650-690 vs 600-620 TFLOP/s for the
+    // 128x128 tile); short-K problems (K = 320..1280 linears) are bound by the fp32 stream traffic of their
+    // epilogue, where the 1-workgroup-per-CU wide tile hides less latency than two 128x128 workgroups
+    return tiles >= 192 && (long)p.taps * p.K >= 2048;
+}
+
+inline bool dma_enabled() {  // CCV_GEMM_DMA=0 falls back to the register-staged loop (tuning aid)
+    static const bool v = [] { const char* e = getenv("CCV_GEMM_DMA"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+inline int slab_depth_override() {  // CCV_GEMM_BK=32|64 forces the slab depth (tuning aid)
+    static const int v = [] { const char* e = getenv("CCV_GEMM_BK"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <bool A_F32, int GATHER>
 int dispatch_tile(const CcvGemm& p, hipStream_t st) {
-    // Largest tile that still yields >= ~1 workgroup per CU (256 CUs); small problems
-    // take the 64x64 tile so the 4x4-latent layers are not left on a handful of CUs.
-    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    if (p.N % 128 == 0 && tiles(128, 128) >= 256) return launch<4, 4, A_F32, GATHER>(p, st);
-    if (p.N % 128 == 0 && tiles(64, 128) >= 256) return launch<2, 4, A_F32, GATHER>(p, st);
-    if (p.N % 64 == 0 && tiles(128, 64) >= 320) return launch<4, 2, A_F32, GATHER>(p, st);
-    return launch<2, 2, A_F32, GATHER>(p, st);
+    int mt, nt;
+    choose_tile(p, mt, nt);
+    if (!A_F32 && wide_applies(p)) return launch_wide<GATHER>(p, st);
+    if (!A_F32 && dma_enabled()) {
+        if (mt == 4 && nt == 4) return launch_dma<4, 4, GATHER>(p, st);
+        if (mt == 2 && nt == 4) return launch_dma<2, 4, GATHER>(p, st);
+        if (mt == 4 && nt == 2) return launch_dma<4, 2, GATHER>(p, st);
+        return launch_dma<2, 2, GATHER>(p, st);
+    }
+    int bk = slab_depth_override();
+    if (bk != 32 && bk != 64) bk = 64;
+    if (bk == 64) {
+        if (mt == 4 && nt == 4) return launch<4, 4, A_F32, GATHER, 64>(p, st);
+        if (mt == 2 && nt == 4) return launch<2, 4, A_F32, GATHER, 64>(p, st);
+        if (mt == 4 && nt == 2) return launch<4, 2, A_F32, GATHER, 64>(p, st);
+        return launch<2, 2, A_F32, GATHER, 64>(p, st);
+    }
+    if (mt == 4 && nt == 4) return launch<4, 4, A_F32, GATHER, 32>(p, st);
+    if (mt == 2 && nt == 4) return launch<2, 4, A_F32, GATHER, 32>(p, st);
+    if (mt == 4 && nt == 2) return launch<4, 2, A_F32, GATHER, 32>(p, st);
+    return launch<2, 2, A_F32, GATHER, 32>(p, st);
 }
 
 }  // namespace

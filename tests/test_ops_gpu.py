@@ -158,6 +158,46 @@ def test_gemm_split_k_paths(ops):
     assert_close(out.reshape(n, hs, hs, cout).permute(0, 3, 1, 2), ref, 2e-3, "split-K conv")
 
 
+def test_gemm_wide_tile_paths(ops):
+    """Shapes that take the 128x320 4-stage LDS-DMA kernel (N % 320 == 0, >= 192 tiles): linear with every
+    epilogue, conv3x3 (padding rows fetch the zero line), temporal conv, GEGLU, ragged M."""
+    from camc2v_amd.pack import interleave_geglu, pack_conv3x3, pack_tconv3
+    M, N, K = 8192 + 40, 960, 2048           # ragged M: last tile partially out of range
+    a, w = rnd(M, K, seed=80), rnd(N, K, seed=81, scale=0.02)
+    bias = rnd(N, seed=82, dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    assert_close(ops.gemm(a, w, bias=bias), ref, 1e-2, "wide linear")
+    res = rnd(M, N, seed=83, dtype=torch.float32)
+    stream = res.clone()
+    ops.gemm(a, w, bias=bias, residual=stream, out_f32=True, out=stream)
+    assert_close(stream, ref + res, 2e-3, "wide in-place residual")
+    M2 = 16384
+    a2 = rnd(M2, 2048, seed=84)
+    wg, bg = rnd(640, 2048, seed=85, scale=0.02), rnd(640, seed=86, dtype=torch.float32)
+    wp, bp = interleave_geglu(wg, bg)
+    val, gate = (a2.float() @ wg.float().t() + bg).chunk(2, dim=-1)
+    assert_close(ops.gemm(a2, wp, bias=bp, geglu=True), val * F.gelu(gate), 1.5e-2, "wide geglu")
+    # conv3x3: 32 frames of 32x32, 64 -> 320 channels, with the per-clip embedding bias
+    n, cin, cout, hs = 32, 256, 320, 32
+    x = rnd(n, cin, hs, hs, seed=87, dtype=torch.float32).to(torch.bfloat16).float()
+    wt = rnd(cout, cin, 3, 3, seed=88, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    cb = rnd(cout, seed=89, dtype=torch.float32)
+    emb = rnd(2, cout, seed=90, dtype=torch.float32)
+    refc = F.conv2d(x, wt, cb, padding=1) + emb.repeat_interleave(16, 0)[:, :, None, None]
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, bias=cb, bias2=emb, ldb2=cout, rows_per_batch=16 * hs * hs,
+                   gather=ops.GATHER_CONV3X3, conv=(hs, hs, hs, hs, 1, 0), out_f32=True)
+    assert_close(out.reshape(n, hs, hs, cout).permute(0, 3, 1, 2), refc, 2e-3, "wide conv3x3")
+    # temporal conv: 2 clips x 16 frames x 1024 pixels
+    b, c, t, hw = 2, 704, 16, 1024
+    xt = rnd(b, c, t, hw, 1, seed=91, dtype=torch.float32).to(torch.bfloat16).float()
+    wtt = rnd(320, c, 3, 1, 1, seed=92, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    reft = F.conv3d(xt, wtt, None, padding=(1, 0, 0))
+    rows = xt[..., 0].permute(0, 2, 3, 1).reshape(-1, c).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_tconv3(wtt), k=c, taps=3, gather=ops.GATHER_TCONV3, tconv=(t, hw), out_f32=True)
+    assert_close(out.reshape(b, t, hw, 320).permute(0, 3, 1, 2), reft[..., 0], 2e-3, "wide tconv3")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from camc2v_amd.lib import CcvError
     with pytest.raises(CcvError):
