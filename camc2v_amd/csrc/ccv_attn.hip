@@ -258,6 +258,325 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
     }
 }
 
+
+// =================================================================================================
+// attn2_kernel: second-generation forward for single-context attention (self / epipolar / temporal).
+//   * a wave owns 64 queries (two 32-row blocks): every K and V^T fragment read from LDS feeds two
+//     MFMAs, halving the LDS bytes per FLOP (the first kernel was LDS-read bound at 2 workgroups/CU);
+//   * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 2-deep ring: the DMA of the
+//     next non-empty tile is in flight while the current one is multiplied; no VGPR staging, no ds_write;
+//     the LDS swizzles are applied to the per-lane SOURCE address (DMA writes 1 KiB pieces linearly);
+//   * softmax: scale folded into one FMA per score, accumulator rescale only when a row maximum moved,
+//     mask bit tests only on 32x32 blocks that are neither full nor out of range.
+// Workgroup = 4 waves = 256 queries of one (batch, head).  Tile flags are given per 128 query rows.
+// =================================================================================================
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+__device__ __attribute__((aligned(16))) unsigned char g_attn_zero_line[16];
+
+__global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, qblk = blockIdx.x;
+    const long bo = b / p.inner, bi = b % p.inner;
+    const int q0 = qblk * 256 + wave * 64;
+    const bool wave_active = q0 < p.Lq;
+
+    bf16x8 qf[2][4];
+    int qi[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = min(q0 + 32 * qb + r, p.Lq - 1);
+        const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)qi[qb] * p.q_ls + head * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    const float sl2 = p.scale * 1.4426950408889634f;
+
+    const int n_reg = (p.kreg != nullptr && p.nreg > 0) ? 1 : 0;
+    const int n_main = (p.Lk + KT - 1) / KT;
+    const int n_total = n_reg + n_main;
+    const bool masked = p.mask_bits != nullptr;
+    const uint8_t* flags = (masked && p.tile_flags) ? p.tile_flags + (long)(b % p.mask_nb) * p.flags_bs : nullptr;
+    const int fq0 = 2 * qblk, fq1 = min(2 * qblk + 1, (p.Lq + 127) / 128 - 1);
+
+    auto next_tile = [&](int it) {  // first schedulable tile index >= it (block-uniform)
+        while (it < n_total) {
+            if (it < n_reg || !flags) break;
+            const int kt = it - n_reg;
+            if (flags[(long)fq0 * p.flags_ktiles + kt] | flags[(long)fq1 * p.flags_ktiles + kt]) break;
+            ++it;
+        }
+        return it;
+    };
+    const uint16_t* kmain = p.k + bo * p.k_bso + bi * p.k_bsi + head * 64;
+    const uint16_t* vmain = p.v + bo * p.v_bso + bi * p.v_bsi + head * 64;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
+
+    auto issue = [&](int it, int stage) {  // DMA tile `it` into ring slot `stage`
+        const uint16_t *kb_, *vb_;
+        long kls, vls;
+        int len, k0;
+        if (it < n_reg) { kb_ = p.kreg + head * 64; vb_ = p.vreg + head * 64; kls = vls = (long)p.H * 64; len = p.nreg; k0 = 0; }
+        else { kb_ = kmain; vb_ = vmain; kls = p.k_ls; vls = p.v_ls; len = p.Lk; k0 = (it - n_reg) * KT; }
+        unsigned char* sK = sm + stage * (2 * KT * 128);
+        unsigned char* sV = sK + KT * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave * 2 + j;             // 8 rows of 128 B
+            const int row = 8 * piece + (lane >> 3), pc = lane & 7;
+            const bool ok = (k0 + row) < len;
+            const uint16_t* gk = ok ? kb_ + (long)(k0 + row) * kls + ((pc ^ ((row >> 1) & 7)) << 3) : zero;
+            const uint16_t* gv = ok ? vb_ + (long)(k0 + row) * vls + ((pc ^ (((row >> 1) & 1) << 2)) << 3) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t*)gk, (lptr_t*)(sK + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)gv, (lptr_t*)(sV + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    float m_run[2] = {NEG_INF, NEG_INF}, l_run[2] = {0.f, 0.f};
+    f32x16 oacc[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
+
+    int cur = next_tile(0), stage = 0;
+    if (cur < n_total) issue(cur, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    while (cur < n_total) {
+        const int nxt = next_tile(cur + 1);
+        if (nxt < n_total) issue(nxt, stage ^ 1);
+
+        if (wave_active) {
+            const bool is_reg = cur < n_reg;
+            const int k0 = is_reg ? 0 : (cur - n_reg) * KT;
+            const int nvalid = min(KT, (is_reg ? p.nreg : p.Lk) - k0);
+            const unsigned char* sK = sm + stage * (2 * KT * 128);
+            const unsigned char* sV = sK + KT * 128;
+            uint32_t mw[2][2];
+            bool on[2][2];
+            bool any_on = false;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    uint32_t w = 0xffffffffu;
+                    if (masked && !is_reg) {
+                        const int wi = (k0 >> 5) + kb;
+                        w = (wi < p.mask_words) ? p.mask_bits[(long)(b % p.mask_nb) * p.mask_bs + (long)qi[qb] * p.mask_words + wi] : 0u;
+                    }
+                    const int left = nvalid - 32 * kb;  // keys of this 32-block that exist
+                    if (left < 32) w = (left <= 0) ? 0u : (w & ((1u << left) - 1u));
+                    mw[qb][kb] = w;
+                    on[qb][kb] = (q0 + 32 * qb < p.Lq) && (__ballot(w != 0u) != 0ull);
+                    any_on |= on[qb][kb];
+                }
+            if (any_on) {
+                f32x16 sacc[2][2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sacc[qb][kb][i] = 0.f;
+                    if (!(on[0][kb] || on[1][kb])) continue;
+                    const int krow = 32 * kb + r;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = 2 * s + hh;
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
+                        if (on[0][kb]) sacc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sacc[0][kb], 0, 0, 0);
+                        if (on[1][kb]) sacc[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sacc[1][kb], 0, 0, 0);
+                    }
+                }
+                bf16x8 pf[2][2][2];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (!(on[qb][0] || on[qb][1])) continue;
+                    // ---- row maximum over the visible scores (raw, unscaled) ----
+                    float tmax = NEG_INF;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        if (!on[qb][kb]) continue;
+                        const bool full = __all(mw[qb][kb] == 0xffffffffu);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ko = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                            float sv = sacc[qb][kb][i];
+                            if (!full) sv = ((mw[qb][kb] >> ko) & 1u) ? sv : NEG_INF;
+                            sacc[qb][kb][i] = sv;
+                            tmax = fmaxf(tmax, sv);
+                        }
+                    }
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+                    const float m_new = fmaxf(m_run[qb], tmax);
+                    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                    if (!__all(m_new == m_run[qb])) {  // some row maximum moved: rescale the running sums
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
+                        l_run[qb] *= alpha;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) oacc[qb][d][i] *= alpha;
+                        m_run[qb] = m_new;
+                    }
+                    float psum = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        if (!on[qb][kb]) continue;
+                        float pv[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][i], sl2, -m_use));  // -inf -> 0
+                            psum += pv[i];
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) pf[qb][kb][s2][j] = (__bf16)pv[8 * s2 + j];
+                    }
+                    l_run[qb] += psum;
+                }
+                // ---- O^T += V^T P^T: each V^T fragment feeds both query blocks ----
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (!(on[0][kb] || on[1][kb])) continue;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int kb0 = 32 * kb + 16 * s2 + 4 * hh;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const int li = lane & 15, g = (lane >> 4) & 1;
+                            const int row0 = kb0 + (li >> 2);
+                            const int colb = (32 * d + 16 * g + 4 * (li & 3)) * 2;  // byte column inside the 128-B row
+                            // rows row0 and row0+8 have the same ((row>>1)&1): one swizzle term serves both reads
+                            const unsigned char* a0 = sV + row0 * 128 + (colb ^ (((row0 >> 1) & 1) << 6));
+                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * 128));
+                            bf16x8 vf;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                            if (on[0][kb]) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kb][s2], oacc[0][d], 0, 0, 0);
+                            if (on[1][kb]) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kb][s2], oacc[1][d], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur = nxt;
+        stage ^= 1;
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        const int q = q0 + 32 * qb + r;
+        if (wave_active && q < p.Lq) {
+            uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)q * p.o_ls + head * 64;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = 32 * d + 8 * g4 + 4 * hh;
+                    uint2 pk = make_uint2(pack_bf16x2(oacc[qb][d][4 * g4] * wgt, oacc[qb][d][4 * g4 + 1] * wgt),
+                                          pack_bf16x2(oacc[qb][d][4 * g4 + 2] * wgt, oacc[qb][d][4 * g4 + 3] * wgt));
+                    *reinterpret_cast<uint2*>(op + dd) = pk;
+                }
+        }
+    }
+}
+
+
+// =================================================================================================
+// attn_temporal_kernel: self attention over <= 16 tokens (the frames of one pixel), one wave per
+// (pixel, head).  HBM/L2-bound: Q and K fragments are loaded straight from the token-major activations
+// (16 rows x 64 B per instruction), S^T = K Q^T is two v_mfma_f32_16x16x32_bf16, the softmax runs on the
+// 16x16 accumulator (4 keys per lane + two cross-lane exchanges), and because the S^T accumulator layout
+// IS the B-operand layout of v_mfma_f32_16x16x16_bf16, P^T feeds O^T = V^T P^T without any lane movement;
+// only V takes a 2 KiB wave-private LDS round trip to be read transposed (ds_read_b64_tr_b16).
+// =================================================================================================
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sV[4][16 * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nitem = (long)p.B * p.H;
+    const long item = (long)blockIdx.x * 4 + wave;
+    const bool active = item < nitem;       // wave-uniform
+    const long it = active ? item : 0;
+    const int head = (int)(it % p.H);
+    const long b = it / p.H;
+    const long bo = b / p.inner, bi = b % p.inner;
+    const int fr = lane & 15, g = lane >> 4;
+    const int T = p.Lk;
+    const int frow = min(fr, T - 1);
+
+    const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)frow * p.q_ls + head * 64 + 8 * g;
+    const uint16_t* kp = p.k + bo * p.k_bso + bi * p.k_bsi + (long)frow * p.k_ls + head * 64 + 8 * g;
+    bf16x8 qf[2], kf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
+        kf[s] = *reinterpret_cast<const bf16x8*>(kp + 32 * s);
+    }
+    // V rows -> wave-private LDS image [16 frames][128 B] (rows >= T zero)
+    const uint16_t* vb = p.v + bo * p.v_bso + bi * p.v_bsi + head * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = lane + 64 * i, row = idx >> 3, c = idx & 7;
+        uint4 vv = make_uint4(0u, 0u, 0u, 0u);
+        if (row < T) vv = *reinterpret_cast<const uint4*>(vb + (long)row * p.v_ls + c * 8);
+        *reinterpret_cast<uint4*>(&sV[wave][row * 128 + c * 16]) = vv;
+    }
+    // S^T[key 4g + r][query fr]
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+    const float sl2 = p.scale * 1.4426950408889634f;
+    float sv[4], m = NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sv[r] = (4 * g + r < T) ? sacc[r] * sl2 : NEG_INF;
+        m = fmaxf(m, sv[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+    short4_t pb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sv[r] - m);
+        l += e;
+        pb[r] = (short)f32_to_bf16(e);
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    __syncthreads();  // V image complete (written by this wave's own lanes; block barrier keeps it simple)
+    const int li = lane & 15;
+    uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)fr * p.o_ls + head * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const unsigned char* a0 = &sV[wave][(4 * g + (li >> 2)) * 128 + (16 * dt + 4 * (li & 3)) * 2];
+        const bf16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+        const short4_t va = __builtin_bit_cast(short4_t, vt);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, o, 0, 0, 0);  // O^T[d = 16 dt + 4 g + r][query fr]
+        if (active && fr < T) {
+            uint2 pk = make_uint2(pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv));
+            *reinterpret_cast<uint2*>(op + 16 * dt) = pk;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
@@ -277,9 +596,17 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(p.nreg <= KT, CCV_ESHAPE, "ccv_attn_fwd: at most 64 register tokens");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gridDim.z is limited to 65535: fold large batches (temporal attention: one batch per pixel)
-    CCV_REQUIRE(p.B <= 65535, CCV_ESHAPE, "ccv_attn_fwd: B=%d exceeds 65535 (split the call)", p.B);
+    const bool temporal_path = p.variant == 0 && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16;
+    CCV_REQUIRE(temporal_path || p.B <= 65535, CCV_ESHAPE, "ccv_attn_fwd: B=%d exceeds 65535 (split the call)", p.B);
     dim3 grid((p.Lq + 127) / 128, p.H, p.B);
-    if (p.variant == 0)
+    if (p.variant == 0 && p.k2 == nullptr && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16) {
+        // frames-of-a-pixel attention: one wave per (batch, head), no key tiling
+        const long items = (long)p.B * p.H;
+        hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
+    } else if (p.variant == 0 && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
+        dim3 grid2((p.Lq + 255) / 256, p.H, p.B);
+        hipLaunchKernelGGL(attn2_kernel, grid2, dim3(256), 0, st, p);
+    } else if (p.variant == 0 || p.variant == 1)
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, p);

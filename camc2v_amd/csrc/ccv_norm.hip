@@ -3,10 +3,9 @@
 // Both are HBM/L2-bound streaming passes: reads are fully coalesced along the channel axis
 // (a row of C channels is contiguous), statistics are fp32.
 //
-// GroupNorm runs as three launches (no global atomics, fixed summation tree => deterministic):
-//   gn_stats    grid (chunks, instances): per-chunk per-group (sum, sumsq) partials
-//   gn_finalize grid (instances): partials -> (mean, rstd) per group
-//   gn_apply    grid (chunks, instances): y = (x - mean) * rstd * gamma + beta [, SiLU] -> bf16
+// GroupNorm runs as two launches (no atomics, fixed summation tree => bitwise reproducible):
+//   gn_stats grid (chunks, instances): per-chunk per-group (sum, sumsq) partials
+//   gn_apply grid (chunks, instances): partials -> (mean, rstd), then y = (x-mean)*rstd*gamma+beta [, SiLU] -> bf16
 // Every load is a 16-byte (4-channel) access; all reductions run in a fixed order, so the result is
 // bitwise reproducible (channels-per-group is even for every layer here, so a channel pair never
 // straddles two groups).
@@ -28,7 +27,7 @@ inline int gn_chunks(int instances, int rows) {
 // threads per block: a multiple of C/4 (each thread owns 4 fixed channels), <= 1024, ~256 when possible
 inline int gn_threads(int C) {
     const int cols = C / 4;
-    int r = 256 / cols;
+    int r = (256 + cols - 1) / cols;   // at least 256 threads (the statistics prologue uses 256)
     if (r < 1) r = 1;
     return cols * r;
 }
@@ -92,29 +91,33 @@ __global__ __launch_bounds__(256) void gn_stats(const void* x, float* partial, i
     }
 }
 
-// grid (instances), 256 threads: 8 threads per group sum the chunk partials
-__global__ __launch_bounds__(256) void gn_finalize(const float* partial, float* stats, int nchunk, float inv_count, float eps) {
-    const int inst = blockIdx.x, g = threadIdx.x >> 3, j = threadIdx.x & 7;
-    float a = 0.f, b = 0.f;
-    for (int c = j; c < nchunk; c += 8) {
-        const float* pp = partial + (((long)inst * nchunk + c) * GN_GROUPS + g) * 2;
-        a += pp[0];
-        b += pp[1];
-    }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    if (j == 0) {
-        const float mean = a * inv_count;
-        const float var = fmaxf(b * inv_count - mean * mean, 0.f);
-        stats[((long)inst * GN_GROUPS + g) * 2] = mean;
-        stats[((long)inst * GN_GROUPS + g) * 2 + 1] = rsqrtf(var + eps);
-    }
-}
-
+// grid (nchunk, instances), 256..1024 threads.  Prologue: the block reduces the chunk partials of its instance to
+// (mean, rstd) per group in a fixed order (8 threads per group + shuffles; every block of an instance computes
+// the same bits), which saves a separate finalize launch per GroupNorm; then y = (x-mean)*rstd*gamma+beta [SiLU].
 template <bool X_F32>
 __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, const float* gamma, const float* beta,
-                                                 const float* stats, int rows_per_instance, int C, int silu) {
+                                                 const float* partial, int rows_per_instance, int C, int silu,
+                                                 float inv_count, float eps) {
+    __shared__ float s_stat[GN_GROUPS * 2];
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    if (threadIdx.x < 256) {
+        const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+        float a = 0.f, b = 0.f;
+        for (int c = j; c < nchunk; c += 8) {
+            const float* pp = partial + (((long)inst * nchunk + c) * GN_GROUPS + g) * 2;
+            a += pp[0];
+            b += pp[1];
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (j == 0) {
+            const float mean = a * inv_count;
+            const float var = fmaxf(b * inv_count - mean * mean, 0.f);
+            s_stat[2 * g] = mean;
+            s_stat[2 * g + 1] = rsqrtf(var + eps);
+        }
+    }
+    __syncthreads();
     const int cols = C >> 2;
     const int col = threadIdx.x % cols, roff = threadIdx.x / cols, R = blockDim.x / cols;
     const int rows_per_chunk = (rows_per_instance + nchunk - 1) / nchunk;
@@ -125,10 +128,8 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = 4 * col + k, g = c / cpg;
-        const float mean = stats[((long)inst * GN_GROUPS + g) * 2];
-        const float rstd = stats[((long)inst * GN_GROUPS + g) * 2 + 1];
-        sc[k] = rstd * gamma[c];
-        sh[k] = beta[c] - mean * sc[k];
+        sc[k] = s_stat[2 * g + 1] * gamma[c];
+        sh[k] = beta[c] - s_stat[2 * g] * sc[k];
     }
     const long base = (long)inst * rows_per_instance * cols;
     uint2* yo = reinterpret_cast<uint2*>(y);
@@ -190,7 +191,6 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     const int nchunk = gn_chunks(instances, rows_per_instance);
     const int nthreads = gn_threads(C);
     float* partial = static_cast<float*>(ws);
-    float* stats = partial + (long)instances * GN_MAX_CHUNKS * GN_GROUPS * 2;
     dim3 grid(nchunk, instances);
     const size_t lds = (size_t)(C / 4) * 4 * sizeof(float) * 5;  // 4 per-wave slabs + the reduced row
     if (x_f32)
@@ -199,12 +199,10 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
         hipLaunchKernelGGL(gn_stats<false>, grid, dim3(256), lds, st, x, partial, rows_per_instance, C);
     CCV_LAUNCH_CHECK("ccv_groupnorm(stats)");
     const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
-    hipLaunchKernelGGL(gn_finalize, dim3(instances), dim3(256), 0, st, partial, stats, nchunk, inv_count, eps);
-    CCV_LAUNCH_CHECK("ccv_groupnorm(finalize)");
     if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, stats, rows_per_instance, C, silu);
+        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
     else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, stats, rows_per_instance, C, silu);
+        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
     CCV_LAUNCH_CHECK("ccv_groupnorm(apply)");
     return CCV_OK;
 }

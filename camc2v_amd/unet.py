@@ -466,6 +466,7 @@ class Downsample(nn.Module, _Prepared):
     def forward_rows(self, x, g):
         pk = self._pk()
         oh, ow = (g.h + 1) // 2, (g.w + 1) // 2
+        x = ops.cast_bf16(x)   # bf16 operand: the conv then runs on the LDS-DMA kernel (fp32 A needs register staging)
         y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_f32=True,
                      gather=ops.GATHER_CONV3X3, conv=(oh, ow, g.h, g.w, 2, 0))
         return y, Geom(g.b, g.t, oh, ow)
@@ -485,6 +486,7 @@ class Upsample(nn.Module, _Prepared):
     def forward_rows(self, x, g):
         pk = self._pk()
         oh, ow = 2 * g.h, 2 * g.w   # nearest 2x is folded into the conv's gather
+        x = ops.cast_bf16(x)
         y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_f32=True,
                      gather=ops.GATHER_CONV3X3, conv=(oh, ow, g.h, g.w, 1, 1))
         return y, Geom(g.b, g.t, oh, ow)

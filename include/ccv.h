@@ -134,7 +134,8 @@ typedef struct CcvAttn {
     int32_t mask_nb;  /* masks exist for mask_nb batches; batch i uses mask i % mask_nb (CFG halves share) */
     const uint8_t* tile_flags; int64_t flags_bs; int32_t flags_ktiles;
     const uint16_t* kreg; const uint16_t* vreg; int32_t nreg;
-    int32_t variant;  /* 0: V via ds_read_tr16_b64, 1: V transposed while staging (debug/fallback) */
+    int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; two-context calls use kernel 1);
+                         1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging */
 } CcvAttn;
 int ccv_attn_fwd(const CcvAttn* p, void* stream);
 

@@ -217,7 +217,7 @@ def ref_attn(q, k, v, mask=None):
     return torch.einsum("bhij,bjhd->bihd", sim.softmax(-1), v)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 5, 1024, 1024), (2, 2, 200, 77), (4, 1, 16, 16), (1, 3, 130, 333)])
 def test_attention_plain(ops, variant, B, H, Lq, Lk):
     q, k, v = rnd(B, Lq, H, 64, seed=20), rnd(B, Lk, H, 64, seed=21), rnd(B, Lk, H, 64, seed=22)
@@ -228,7 +228,7 @@ def test_attention_plain(ops, variant, B, H, Lq, Lk):
     assert_close(out.reshape(B, Lq, H, 64), ref, 1.5e-2, f"attention v{variant} {B},{H},{Lq},{Lk}")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention_fused_qkv_and_dual_context(ops, variant):
     """q/k/v as column slices of one fused [rows, 3C] projection; text + gated image context with
     K/V shared by all frames of a clip (inner batch stride 0)."""
@@ -257,10 +257,12 @@ def test_attention_fused_qkv_and_dual_context(ops, variant):
     assert_close(out.reshape(B, hw, H, 64), ref, 1.5e-2, "dual context")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-def test_attention_temporal_strided(ops, variant):
-    """batch = (clip, pixel), tokens = frames with stride hw*C (token-major activations untouched)."""
-    clips, T, hw, H = 2, 16, 24, 3
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("T", [16, 9])
+def test_attention_temporal_strided(ops, variant, T):
+    """batch = (clip, pixel), tokens = frames with stride hw*C (token-major activations untouched).
+    variant 0 takes the one-wave-per-(pixel, head) kernel for T <= 16."""
+    clips, hw, H = 2, 25, 3
     C = H * 64
     qkv = rnd(clips * T * hw, 3 * C, seed=27)
     ld = 3 * C
@@ -274,7 +276,7 @@ def test_attention_temporal_strided(ops, variant):
     assert_close(got, ref, 1.5e-2, "temporal")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("L,density", [(1024, 0.04), (320, 0.3), (48, 0.5)])
 def test_attention_masked_register_tokens(ops, variant, L, density):
     """Epipolar form: bit mask + tile flags + always-visible register tokens; mask shared by the
