@@ -274,6 +274,7 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 __device__ __attribute__((aligned(16))) unsigned char g_attn_zero_line[16];
 
+template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
     const int tid = threadIdx.x;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     const int n_reg = (p.kreg != nullptr && p.nreg > 0) ? 1 : 0;
     const int n_main = (p.Lk + KT - 1) / KT;
     const int n_total = n_reg + n_main;
-    const bool masked = p.mask_bits != nullptr;
+    constexpr bool masked = MASKED;
     const uint8_t* flags = (masked && p.tile_flags) ? p.tile_flags + (long)(b % p.mask_nb) * p.flags_bs : nullptr;
     const int fq0 = 2 * qblk, fq1 = min(2 * qblk + 1, (p.Lq + 127) / 128 - 1);
 
@@ -344,13 +345,32 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
 
+    // mask words of a tile: [query block][32-key block]; loaded one tile ahead so their latency hides behind
+    // the current tile's math (register tokens and unmasked calls see all-ones)
+    auto load_words = [&](int it, uint32_t (&w)[2][2]) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                w[qb][kb] = 0xffffffffu;
+                if (masked && it >= n_reg && it < n_total) {
+                    const int wi = (((it - n_reg) * KT) >> 5) + kb;
+                    w[qb][kb] = (wi < p.mask_words)
+                                    ? p.mask_bits[(long)(b % p.mask_nb) * p.mask_bs + (long)qi[qb] * p.mask_words + wi] : 0u;
+                }
+            }
+    };
+
     int cur = next_tile(0), stage = 0;
+    uint32_t mwc[2][2], mwn[2][2];
     if (cur < n_total) issue(cur, 0);
+    load_words(cur, mwc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     while (cur < n_total) {
         const int nxt = next_tile(cur + 1);
         if (nxt < n_total) issue(nxt, stage ^ 1);
+        load_words(nxt, mwn);
 
         if (wave_active) {
             const bool is_reg = cur < n_reg;
@@ -365,11 +385,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    uint32_t w = 0xffffffffu;
-                    if (masked && !is_reg) {
-                        const int wi = (k0 >> 5) + kb;
-                        w = (wi < p.mask_words) ? p.mask_bits[(long)(b % p.mask_nb) * p.mask_bs + (long)qi[qb] * p.mask_words + wi] : 0u;
-                    }
+                    uint32_t w = mwc[qb][kb];
                     const int left = nvalid - 32 * kb;  // keys of this 32-block that exist
                     if (left < 32) w = (left <= 0) ? 0u : (w & ((1u << left) - 1u));
                     mw[qb][kb] = w;
@@ -377,75 +393,74 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                     any_on |= on[qb][kb];
                 }
             if (any_on) {
-                f32x16 sacc[2][2];
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                // one online-softmax step per 32-key block: S^T (8 MFMAs) -> softmax -> O^T += V^T P^T (8 MFMAs);
+                // every K / V^T fragment read from LDS feeds both query blocks
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) sacc[qb][kb][i] = 0.f;
-                    if (!(on[0][kb] || on[1][kb])) continue;
+                    const bool on0 = on[0][kb], on1 = on[1][kb];
+                    if (!(on0 || on1)) continue;
+                    f32x16 sa0 = zero16, sa1 = zero16;
                     const int krow = 32 * kb + r;
+                    if (!MASKED || (on0 && on1)) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int c = 2 * s + hh;
-                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
-                        if (on[0][kb]) sacc[0][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sacc[0][kb], 0, 0, 0);
-                        if (on[1][kb]) sacc[1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sacc[1][kb], 0, 0, 0);
-                    }
-                }
-                bf16x8 pf[2][2][2];
+                        for (int s = 0; s < 4; ++s) {
+                            const int c = 2 * s + hh;
+                            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
+                            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
+                            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
+                        }
+                    } else {
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    if (!(on[qb][0] || on[qb][1])) continue;
-                    // ---- row maximum over the visible scores (raw, unscaled) ----
-                    float tmax = NEG_INF;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        if (!on[qb][kb]) continue;
-                        const bool full = __all(mw[qb][kb] == 0xffffffffu);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int ko = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                            float sv = sacc[qb][kb][i];
-                            if (!full) sv = ((mw[qb][kb] >> ko) & 1u) ? sv : NEG_INF;
-                            sacc[qb][kb][i] = sv;
-                            tmax = fmaxf(tmax, sv);
+                        for (int s = 0; s < 4; ++s) {
+                            const int c = 2 * s + hh;
+                            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
+                            if (on0) sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
+                            else     sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
                         }
                     }
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
-                    const float m_new = fmaxf(m_run[qb], tmax);
-                    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                    if (!__all(m_new == m_run[qb])) {  // some row maximum moved: rescale the running sums
-                        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
-                        l_run[qb] *= alpha;
+                    bf16x8 pf0[2], pf1[2];
+                    auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
+                        float tmax = NEG_INF;
+                        if (__builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu))) {
 #pragma unroll
-                        for (int d = 0; d < 2; ++d)
+                            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sa[i]);
+                        } else {
+                            const uint32_t wsh = w >> (4 * hh);
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) oacc[qb][d][i] *= alpha;
-                        m_run[qb] = m_new;
-                    }
-                    float psum = 0.f;
+                            for (int i = 0; i < 16; ++i) {
+                                const float sv = ((wsh >> ((i & 3) + 8 * (i >> 2))) & 1u) ? sa[i] : NEG_INF;
+                                sa[i] = sv;
+                                tmax = fmaxf(tmax, sv);
+                            }
+                        }
+                        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+                        const float m_new = fmaxf(m_r, tmax);
+                        const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                        if (!__all(m_new == m_r)) {  // some row maximum moved: rescale the running sums
+                            const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
+                            l_r *= alpha;
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        if (!on[qb][kb]) continue;
+                            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) oa[d][i] *= alpha;
+                            m_r = m_new;
+                        }
+                        float psum = 0.f;
                         float pv[16];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][i], sl2, -m_use));  // -inf -> 0
+                            pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[i], sl2, -m_use));  // -inf -> 0
                             psum += pv[i];
                         }
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) pf[qb][kb][s2][j] = (__bf16)pv[8 * s2 + j];
-                    }
-                    l_run[qb] += psum;
-                }
-                // ---- O^T += V^T P^T: each V^T fragment feeds both query blocks ----
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if (!(on[0][kb] || on[1][kb])) continue;
+                            for (int j = 0; j < 8; ++j) pfo[s2][j] = (__bf16)pv[8 * s2 + j];
+                        l_r += psum;
+                    };
+                    if (!MASKED || on0) softmax_block(sa0, mw[0][kb], m_run[0], l_run[0], oacc[0], pf0);
+                    if (!MASKED || on1) softmax_block(sa1, mw[1][kb], m_run[1], l_run[1], oacc[1], pf1);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         const int kb0 = 32 * kb + 16 * s2 + 4 * hh;
@@ -461,8 +476,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                             bf16x8 vf;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                            if (on[0][kb]) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kb][s2], oacc[0][d], 0, 0, 0);
-                            if (on[1][kb]) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kb][s2], oacc[1][d], 0, 0, 0);
+                            if (!MASKED || on0) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0[s2], oacc[0][d], 0, 0, 0);
+                            if (!MASKED || on1) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1[s2], oacc[1][d], 0, 0, 0);
                         }
                     }
                 }
@@ -472,6 +487,10 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         __syncthreads();
         cur = nxt;
         stage ^= 1;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) mwc[qb][kb] = mwn[qb][kb];
     }
 
 #pragma unroll
@@ -605,7 +624,10 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
         hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
     } else if (p.variant == 0 && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
         dim3 grid2((p.Lq + 255) / 256, p.H, p.B);
-        hipLaunchKernelGGL(attn2_kernel, grid2, dim3(256), 0, st, p);
+        if (p.mask_bits)
+            hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL(attn2_kernel<false>, grid2, dim3(256), 0, st, p);
     } else if (p.variant == 0 || p.variant == 1)
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, p);
     else
