@@ -23,6 +23,8 @@ if ROOT not in sys.path:
 SEED = 20230211          # reference default seed (main/trainer.py:21)
 N_CONTEXT = 2            # extra context frames -> cond context 77 + 256*(1+N) tokens
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
+# (2 * 8.334e8 + 4.712e8) KB per clip: profiles/r01_rocprofv3_pmc_{FETCH,WRITE}_SIZE_bench_eager.txt
+TRAFFIC_BYTES_PER_CLIP = (2 * 8.333943e8 + 4.712476e8) * 1024
 
 
 def build_model(device, unet_params=None):
@@ -109,6 +111,60 @@ def cpu_baseline(model, device):
                 seconds_per_forward=dt), dict(rel_l2=rel_l2, max_rel=max_rel, case="full-size UNet forward, no camera, vs fp32 oracle")
 
 
+def timed_clips(sample_fn, steps, warmup, dist=None, sync=None):
+    """W untimed + exactly K timed calls of `sample_fn`, bracketed by sync + barrier + sync on both sides;
+    returns (max-over-ranks wall seconds, this rank's wall seconds, last output).  Device independent so the
+    multi-process logic is testable on CPU with gloo."""
+    sync = sync or (lambda: None)
+
+    def fence():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        sample_fn()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = sample_fn()
+    fence()
+    mine = time.perf_counter() - t0
+    worst = mine
+    if dist is not None:
+        tt = torch.tensor([mine], dtype=torch.float64)
+        if sync is not None and torch.cuda.is_available() and dist.get_backend() == "nccl":
+            tt = tt.cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        worst = float(tt.item())
+    return worst, mine, out
+
+
+def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None):
+    from camc2v_amd import configs
+    clips = steps * world
+    tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
+    per_clip_s = (dev_ms / 1e3 / steps) if dev_ms is not None else elapsed / steps
+    achieved = tf_per_clip / per_clip_s  # one GPU's rate: algorithmic TFLOP of a clip / its device time
+    return {
+        "metric": "denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
+        "value": 16.0 * clips / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, "
+                               "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights",
+                   "clips_per_gpu": 1, "parallelism": f"clip-dp{world}", "launch": "hipGraph" if use_graph else "eager"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": TRAFFIC_BYTES_PER_CLIP,
+                     "kernel": "whole DDIM path (all launches of 25 CFG steps); algorithmic 375 TFLOP/clip, masks counted "
+                               "dense; traffic = L2<->fabric bytes per clip from rocprofv3 PMC passes (profiles/r01_*pmc*): "
+                               "2*FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included",
+                     "device_ms_per_clip": 1e3 * per_clip_s},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,49 +192,23 @@ def main():
     cond, uncond, fs, x_T, noises = synthetic_inputs(model, device, rank=rank)
     use_graph = not args.no_graph
 
-    for _ in range(args.warmup):
-        sample_clip(model, cond, uncond, fs, x_T, noises, use_graph)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        out = sample_clip(model, cond, uncond, fs, x_T, noises, use_graph)
+    state = {"n": 0}
+
+    def one_clip():
+        if state["n"] == args.warmup:          # first timed clip: HIP event on the launch stream
+            ev0.record()
+        state["n"] += 1
+        return sample_clip(model, cond, uncond, fs, x_T, noises, use_graph)
+
+    elapsed, _, out = timed_clips(one_clip, args.steps, args.warmup, dist, torch.cuda.synchronize)
     ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()
     dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        from camc2v_amd import configs
-        clips = args.steps * world
-        tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
-        achieved = tf_per_clip * args.steps / (dev_ms / 1e3)  # this rank's device time (HIP events on the launch stream)
-        line = {
-            "metric": "denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
-            "value": 16.0 * clips / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, "
-                                   "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights",
-                       "clips_per_gpu": 1, "parallelism": f"clip-dp{world}", "launch": "hipGraph" if use_graph else "eager"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "kernel": "whole DDIM path (all launches of 25 CFG steps); algorithmic 375 TFLOP/clip, masks counted dense",
-                         "device_ms_per_clip": dev_ms / args.steps},
-        }
+        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_full_size"] = cpu_baseline(model, device)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output (kernel trace, kernel stats, PMC counter collection) into small text
+summaries that can be committed under profiles/.
+
+    python tools/summarize_rocprof.py <rocprof_out_dir> <summary.txt> [--delete]
+"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:90]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    out = []
+    traces = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
+    counters = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
+    if traces:
+        agg = collections.defaultdict(lambda: [0, 0, 10 ** 18, 0])
+        t_first, t_last = 10 ** 30, 0
+        for r in csv.DictReader(open(traces[0])):
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += d
+            a[2] = min(a[2], d)
+            a[3] = max(a[3], d)
+            t_first, t_last = min(t_first, int(r["Start_Timestamp"])), max(t_last, int(r["End_Timestamp"]))
+        tot = sum(a[1] for a in agg.values())
+        out.append(f"# kernel trace: {sum(a[0] for a in agg.values())} dispatches, {tot / 1e6:.2f} ms of kernel time, "
+                   f"{(t_last - t_first) / 1e6:.2f} ms first-start to last-end")
+        out.append(f"{'kernel':92s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            out.append(f"{k:92s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.1f} {a[2] / 1e3:9.1f} {a[3] / 1e3:9.1f} {100 * a[1] / tot:6.2f}")
+    if counters:
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        calls = collections.defaultdict(int)
+        for r in csv.DictReader(open(counters[0])):
+            k = short(r["Kernel_Name"])
+            per[r["Counter_Name"]][k] += float(r["Counter_Value"])
+            calls[(r["Counter_Name"], k)] += 1
+        for cname, d in per.items():
+            tot = sum(d.values())
+            out.append(f"# counter {cname}: total {tot:.6e} over {sum(calls[(cname, k)] for k in d)} dispatches")
+            for k, v in sorted(d.items(), key=lambda kv: -kv[1])[:40]:
+                out.append(f"{k:92s} {calls[(cname, k)]:7d} {v:16.6e} {v / max(calls[(cname, k)], 1):14.4e}")
+    os.makedirs(os.path.dirname(os.path.abspath(dst)), exist_ok=True)
+    open(dst, "w").write("\n".join(out) + "\n")
+    if "--delete" in sys.argv:
+        shutil.rmtree(src, ignore_errors=True)
+    print("\n".join(out[:12]))
+
+
+if __name__ == "__main__":
+    main()
