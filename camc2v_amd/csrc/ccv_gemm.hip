@@ -352,23 +352,28 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
         }
     }
     const int ldw = p.taps * p.K;
-    const uint16_t* b_ptr[BI];
-#pragma unroll
-    for (int j = 0; j < BI; ++j) {
-        const int r = 8 * (4 * j + wave) + lrow;
-        const int n = n0 + r;
-        b_ptr[j] = (n < p.N) ? p.W + (long)n * ldw + (lchunk ^ ((r >> 1) & 7)) * 8 : nullptr;
-    }
     const int slabs_per_tap = p.K / BK;
     const int nslab_all = p.taps * slabs_per_tap;
     const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
     const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
-
-    auto issue = [&](int s, int buf) {
-        const int tap = s / slabs_per_tap;
-        const int kc = (s - tap * slabs_per_tap) * BK;
+    // Per-lane DMA source pointers advance by one slab per issue; the gather is re-evaluated only when the tap
+    // changes (9 / 3 / 1 times per tile), so the steady-state loop carries two 64-bit adds per DMA instruction
+    // instead of the divisions, bounds tests and 64-bit multiplies of the gather.
+    const uint16_t* b_ptr[BI];
+    int b_step[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int r = 8 * (4 * j + wave) + lrow;
+        const int n = n0 + r;
+        const bool ok = n < p.N;
+        b_ptr[j] = ok ? p.W + (long)n * ldw + (long)s_begin * BK + (lchunk ^ ((r >> 1) & 7)) * 8 : zero;
+        b_step[j] = ok ? BK : 0;
+    }
+    const uint16_t* a_ptr[AI];
+    int a_step[AI];
+    auto set_tap = [&](int tap, int kc) {
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
             long src = -1;
@@ -386,14 +391,31 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
                     if (f >= 0 && f < p.frames) src = (long)a_base[j] + (long)(tap - 1) * p.hw;
                 }
             }
-            const uint16_t* g = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sA + (buf * BM + 8 * (4 * j + wave)) * 128), 16, 0, 0);
+            a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
+            a_step[j] = (src >= 0) ? BK : 0;
+        }
+    };
+    int tap_cur = s_begin / slabs_per_tap;
+    int slab_in_tap = s_begin - tap_cur * slabs_per_tap;
+    set_tap(tap_cur, slab_in_tap * BK);
+
+    auto issue = [&](int buf) {  // DMA the next slab (slabs are issued strictly in order)
+        if (slab_in_tap == slabs_per_tap) {
+            slab_in_tap = 0;
+            ++tap_cur;
+            set_tap(tap_cur, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t*)a_ptr[j], (lptr_t*)(sA + (buf * BM + 8 * (4 * j + wave)) * 128), 16, 0, 0);
+            a_ptr[j] += a_step[j];
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            const uint16_t* g = b_ptr[j] ? b_ptr[j] + s * BK : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sB + (buf * BN + 8 * (4 * j + wave)) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)b_ptr[j], (lptr_t*)(sB + (buf * BN + 8 * (4 * j + wave)) * 128), 16, 0, 0);
+            b_ptr[j] += b_step[j];
         }
+        ++slab_in_tap;
     };
 
     f32x4 acc[MT][NT];
@@ -403,12 +425,12 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
 
-    issue(s_begin, 0);
+    issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) issue(s + 1, buf ^ 1);
+        if (s + 1 < s_end) issue(buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + fg;
@@ -526,24 +548,21 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
         }
     }
     const int ldw = p.taps * p.K;
-    const uint16_t* b_ptr[BI];
-#pragma unroll
-    for (int j = 0; j < BI; ++j) {
-        const int r = 16 * (4 * j + wave) + lrow;
-        b_ptr[j] = p.W + (long)(n0 + r) * ldw + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
-    }
     const int slabs_per_tap = p.K / WIDE_BK;
     const int nslab_all = p.taps * slabs_per_tap;
     const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
     const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
-
-    auto issue = [&](int s, int stage) {
-        unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
-        unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
-        const int tap = s / slabs_per_tap;
-        const int kc = (s - tap * slabs_per_tap) * WIDE_BK;
+    const uint16_t* b_ptr[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int r = 16 * (4 * j + wave) + lrow;
+        b_ptr[j] = p.W + (long)(n0 + r) * ldw + (long)s_begin * WIDE_BK + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
+    }
+    const uint16_t* a_ptr[AI];
+    int a_step[AI];
+    auto set_tap = [&](int tap, int kc) {   // gather re-evaluated only when the tap changes
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
             long src = -1;
@@ -561,12 +580,33 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
                     if (f >= 0 && f < p.frames) src = (long)a_base[j] + (long)(tap - 1) * p.hw;
                 }
             }
-            const uint16_t* g = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sA + 16 * (4 * j + wave) * 64), 16, 0, 0);
+            a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
+            a_step[j] = (src >= 0) ? WIDE_BK : 0;
+        }
+    };
+    int tap_cur = s_begin / slabs_per_tap;
+    int slab_in_tap = s_begin - tap_cur * slabs_per_tap;
+    set_tap(tap_cur, slab_in_tap * WIDE_BK);
+
+    auto issue = [&](int stage) {  // DMA the next slab into ring slot `stage` (slabs are issued strictly in order)
+        if (slab_in_tap == slabs_per_tap) {
+            slab_in_tap = 0;
+            ++tap_cur;
+            set_tap(tap_cur, 0);
+        }
+        unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
+        unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t*)a_ptr[j], (lptr_t*)(sA + 16 * (4 * j + wave) * 64), 16, 0, 0);
+            a_ptr[j] += a_step[j];
         }
 #pragma unroll
-        for (int j = 0; j < BI; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(b_ptr[j] + s * WIDE_BK), (lptr_t*)(sB + 16 * (4 * j + wave) * 64), 16, 0, 0);
+        for (int j = 0; j < BI; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t*)b_ptr[j], (lptr_t*)(sB + 16 * (4 * j + wave) * 64), 16, 0, 0);
+            b_ptr[j] += WIDE_BK;
+        }
+        ++slab_in_tap;
     };
 
     f32x4 acc[MT][NT];
@@ -579,7 +619,7 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
     // prologue: three slabs in flight
 #pragma unroll
     for (int k = 0; k < WIDE_ST - 1; ++k)
-        if (s_begin + k < s_end) issue(s_begin + k, k);
+        if (s_begin + k < s_end) issue(k);
 
     for (int s = s_begin; s < s_end; ++s) {
         const int stage = (s - s_begin) & (WIDE_ST - 1);
@@ -592,7 +632,7 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         // the stage consumed in the previous iteration is free now: every wave passed the barrier after reading it
-        if (s + WIDE_ST - 1 < s_end) issue(s + WIDE_ST - 1, (stage + WIDE_ST - 1) & (WIDE_ST - 1));
+        if (s + WIDE_ST - 1 < s_end) issue((stage + WIDE_ST - 1) & (WIDE_ST - 1));
         const unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
         const unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
         bf16x8 fa[MT];
