@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     int qi[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        qi[qb] = min(q0 + 32 * qb + r, p.Lq - 1);
-        const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)qi[qb] * p.q_ls + head * 64 + 8 * hh;
+        qi[qb] = min(q0 + 32 * qb + r, p.Lq - 1);   // index in mask / schedule order
+        const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)ccv_patch_row(qi[qb], p.perm_hw, p.perm_w) * p.q_ls + head * 64 + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
@@ -329,8 +329,9 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
             const int piece = wave * 2 + j;             // 8 rows of 128 B
             const int row = 8 * piece + (lane >> 3), pc = lane & 7;
             const bool ok = (k0 + row) < len;
-            const uint16_t* gk = ok ? kb_ + (long)(k0 + row) * kls + ((pc ^ ((row >> 1) & 7)) << 3) : zero;
-            const uint16_t* gv = ok ? vb_ + (long)(k0 + row) * vls + ((pc ^ (((row >> 1) & 1) << 2)) << 3) : zero;
+            const long krow_g = (it < n_reg) ? (long)(k0 + row) : (long)ccv_patch_row(k0 + row, p.perm_hw, p.perm_w);
+            const uint16_t* gk = ok ? kb_ + krow_g * kls + ((pc ^ ((row >> 1) & 7)) << 3) : zero;
+            const uint16_t* gv = ok ? vb_ + krow_g * vls + ((pc ^ (((row >> 1) & 1) << 2)) << 3) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t*)gk, (lptr_t*)(sK + piece * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t*)gv, (lptr_t*)(sV + piece * 1024), 16, 0, 0);
         }
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         const int q = q0 + 32 * qb + r;
         if (wave_active && q < p.Lq) {
-            uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)q * p.o_ls + head * 64;
+            uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)ccv_patch_row(q, p.perm_hw, p.perm_w) * p.o_ls + head * 64;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -613,12 +614,15 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
     CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
     CCV_REQUIRE(p.nreg <= KT, CCV_ESHAPE, "ccv_attn_fwd: at most 64 register tokens");
+    CCV_REQUIRE(p.perm_w == 0 || (p.variant == 0 && !p.k2 && p.perm_w % 8 == 0 && p.perm_hw > 0 && p.perm_hw % (4 * p.perm_w) == 0 &&
+                                  p.Lq % p.perm_hw == 0 && p.Lk % p.perm_hw == 0),
+                CCV_ESHAPE, "ccv_attn_fwd: patch order needs the single-context kernel, W %% 8 == 0, H %% 4 == 0 and whole frames");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gridDim.z is limited to 65535: fold large batches (temporal attention: one batch per pixel)
-    const bool temporal_path = p.variant == 0 && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16;
+    const bool temporal_path = p.variant == 0 && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16 && p.perm_w == 0;
     CCV_REQUIRE(temporal_path || p.B <= 65535, CCV_ESHAPE, "ccv_attn_fwd: B=%d exceeds 65535 (split the call)", p.B);
     dim3 grid((p.Lq + 127) / 128, p.H, p.B);
-    if (p.variant == 0 && p.k2 == nullptr && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16) {
+    if (temporal_path) {
         // frames-of-a-pixel attention: one wave per (batch, head), no key tiling
         const long items = (long)p.B * p.H;
         hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);

@@ -56,6 +56,16 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
+// permuted token index -> stored row: frames of `hw` tokens, `w` wide, walked in 4x8-pixel patches (w == 0: identity)
+__host__ __device__ __forceinline__ int ccv_patch_row(int idx, int hw, int w) {
+    if (w == 0) return idx;
+    const int f = idx / hw, rem = idx - f * hw;
+    const int patch = rem >> 5, within = rem & 31;
+    const int ppr = w >> 3;                       // patches per patch-row
+    const int py = patch / ppr, px = patch - py * ppr;
+    return f * hw + (py * 4 + (within >> 3)) * w + px * 8 + (within & 7);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -171,16 +171,23 @@ __global__ void ddim_update_kernel(const float* x, const float* e_c, const float
 // ---- epipolar mask preparation -----------------------------------------------------------
 // bool bytes [B, Lq, Lk] -> words [B, Lq, W]; one thread per word (32 contiguous bytes).
 __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* flags, int Lq, int Lk, int words,
-                                 int ktiles, int64_t nwords_total) {
+                                 int ktiles, int64_t nwords_total, int perm_hw, int perm_w) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords_total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int w = (int)(i % words);
         const int64_t rowi = i / words;  // b * Lq + q
         const int q = (int)(rowi % Lq);
         const int64_t b = rowi / Lq;
-        const uint8_t* src = mask + rowi * Lk + (int64_t)w * 32;
         uint32_t word = 0;
         const int nk = min(32, Lk - w * 32);
+        if (perm_w) {  // patch order: output row q / bit j <-> stored row patch_row(q) / column patch_row(32 w + j)
+            const uint8_t* srow = mask + (b * Lq + ccv_patch_row(q, perm_hw, perm_w)) * (int64_t)Lk;
+            for (int j = 0; j < nk; ++j) word |= (srow[ccv_patch_row(w * 32 + j, perm_hw, perm_w)] ? 1u : 0u) << j;
+            bits[i] = word;
+            if (word && flags) flags[(b * ((Lq + 127) / 128) + q / 128) * ktiles + (w >> 1)] = 1;
+            continue;
+        }
+        const uint8_t* src = mask + rowi * Lk + (int64_t)w * 32;
         if (nk == 32 && (((uintptr_t)src) & 15) == 0) {
             const uint4 lo = reinterpret_cast<const uint4*>(src)[0], hi = reinterpret_cast<const uint4*>(src)[1];
             const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -200,7 +207,7 @@ __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* f
 // Arithmetic mirrors model/camcontexti2v.py:229-239 in fp32 without FMA contraction:
 //   l = F x1; l /= ||l_xy||; visible <=> |l . x2| < d*sqrt(2)/2.
 __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, int T, int H, int W, float d,
-                                     int words, int ktiles, int64_t nwords_total) {
+                                     int words, int ktiles, int64_t nwords_total, int perm_w) {
 #pragma clang fp contract(off)
     const int HW = H * W, L = T * HW;
     const float thr = d * 0.70710678118654752440f;
@@ -210,15 +217,16 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
         const int64_t rowi = i / words;
         const int q = (int)(rowi % L);
         const int64_t b = rowi / L;
-        const int t1 = q / HW, p1 = q % HW;
+        const int qs = ccv_patch_row(q, HW, perm_w);   // stored (raster) token of output row q
+        const int t1 = qs / HW, p1 = qs % HW;
         const float x1 = (float)(p1 % W) * d + d / 2.0f - 0.5f;
         const float y1 = (float)(p1 / W) * d + d / 2.0f - 0.5f;
         uint32_t word = 0;
         int t2_cached = -1;
         float l0 = 0.f, l1 = 0.f, l2 = 0.f;
         for (int j = 0; j < 32; ++j) {
-            const int key = w * 32 + j;
-            if (key >= L) break;
+            if (w * 32 + j >= L) break;
+            const int key = ccv_patch_row(w * 32 + j, HW, perm_w);
             const int t2 = key / HW, p2 = key % HW;
             if (t2 != t2_cached) {
                 const float* f = F + ((b * T + t1) * T + t2) * 9;
@@ -324,23 +332,27 @@ extern "C" int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* 
     return CCV_OK;
 }
 
-extern "C" int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, int32_t B, int32_t Lq, int32_t Lk, void* stream) {
+extern "C" int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, int32_t B, int32_t Lq, int32_t Lk,
+                             int32_t perm_hw, int32_t perm_w, void* stream) {
     CCV_REQUIRE(mask && bits && B > 0 && Lq > 0 && Lk > 0, CCV_EINVAL, "ccv_pack_mask: bad args");
+    CCV_REQUIRE(perm_w == 0 || (perm_w % 8 == 0 && perm_hw > 0 && perm_hw % (4 * perm_w) == 0 && Lq % perm_hw == 0 && Lk % perm_hw == 0),
+                CCV_ESHAPE, "ccv_pack_mask: patch order needs W %% 8 == 0, H %% 4 == 0 and whole frames");
     const int words = (Lk + 31) / 32, ktiles = (Lk + 63) / 64;
     const int64_t n = (int64_t)B * Lq * words;
-    hipLaunchKernelGGL(pack_mask_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), mask, bits, flags, Lq, Lk, words, ktiles, n);
+    hipLaunchKernelGGL(pack_mask_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), mask, bits, flags, Lq, Lk, words, ktiles, n, perm_hw, perm_w);
     CCV_LAUNCH_CHECK("ccv_pack_mask");
     return CCV_OK;
 }
 
 extern "C" int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, int32_t B, int32_t T, int32_t H,
-                                      int32_t W, int32_t downsample, void* stream) {
+                                      int32_t W, int32_t downsample, int32_t patch_order, void* stream) {
     CCV_REQUIRE(F && bits && B > 0 && T > 0 && H > 0 && W > 0 && downsample > 0, CCV_EINVAL, "ccv_epipolar_mask_bits: bad args");
+    CCV_REQUIRE(!patch_order || (W % 8 == 0 && H % 4 == 0), CCV_ESHAPE, "ccv_epipolar_mask_bits: patch order needs W %% 8 == 0 and H %% 4 == 0");
     const int L = T * H * W;
     const int words = (L + 31) / 32, ktiles = (L + 63) / 64;
     const int64_t n = (int64_t)B * L * words;
     hipLaunchKernelGGL(epipolar_bits_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), F, bits, flags, T, H, W,
-                       (float)downsample, words, ktiles, n);
+                       (float)downsample, words, ktiles, n, patch_order ? W : 0);
     CCV_LAUNCH_CHECK("ccv_epipolar_mask_bits");
     return CCV_OK;
 }

@@ -142,35 +142,67 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
     }
 }
 
-// one wave per row, C/64 elements per lane (C <= 2048)
+// 16 lanes per row (4 rows per wave, 16 rows per 256-thread block); a lane owns float4 columns lane16 + 16*i,
+// so every load instruction reads 256 contiguous bytes of each of its 4 rows and every store writes 128.
+// Two-pass statistics on registers (mean, then centred sum of squares), reduced over the 16 lanes with shuffles.
+// LN_MAX4 = float4 columns per lane the instance is compiled for (C <= 64 * LN_MAX4): 5 covers C = 320 with 20
+// live registers instead of 128, which keeps 8 waves per SIMD resident for this bandwidth-bound pass.
+template <int LN_MAX4>
 __global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, const float* gamma, const float* beta,
                                                  int rows, int C, float eps, const uint16_t* addend, int addend_rows, uint16_t* y2) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const int per = C >> 6;
-    const float* xr = x + (long)row * C;
-    float v[32];
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const int cols = C >> 2;                 // float4 columns per row
+    const int per = (cols + 15) >> 4;        // per lane
+    const bool live = row < rows;
+    const float4* xr = reinterpret_cast<const float4*>(x) + (long)(live ? row : 0) * cols;
+    float4 v[LN_MAX4];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        v[i] = 0.f;
-        if (i < per) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    for (int i = 0; i < LN_MAX4; ++i) {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = l16 + 16 * i;
+        if (i < per && c < cols) {
+            v[i] = xr[c];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
     }
-    const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i)
-        if (i < per) { const float d = v[i] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-    for (int i = 0; i < 32; ++i)
-        if (i < per) {
-            const int c = lane + 64 * i;
-            const float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
-            y[(long)row * C + c] = f32_to_bf16(o);
-            if (y2) y2[(long)row * C + c] = f32_to_bf16(o + bf16_to_f32(addend[(long)(row % addend_rows) * C + c]));
+    for (int i = 0; i < LN_MAX4; ++i) {
+        const int c = l16 + 16 * i;
+        if (i < per && c < cols) {
+            const float a = v[i].x - mean, b = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+            q += (a * a + b * b) + (d * d + e * e);
         }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+    uint2* yo = reinterpret_cast<uint2*>(y) + (long)row * cols;
+    uint2* y2o = y2 ? reinterpret_cast<uint2*>(y2) + (long)row * cols : nullptr;
+    const uint2* ad = addend ? reinterpret_cast<const uint2*>(addend) + (long)(row % addend_rows) * cols : nullptr;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAX4; ++i) {
+        const int c = l16 + 16 * i;
+        if (i < per && c < cols) {
+            const float4 g = g4[c], bb = b4[c];
+            const float o0 = (v[i].x - mean) * rstd * g.x + bb.x, o1 = (v[i].y - mean) * rstd * g.y + bb.y;
+            const float o2 = (v[i].z - mean) * rstd * g.z + bb.z, o3 = (v[i].w - mean) * rstd * g.w + bb.w;
+            yo[c] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            if (y2o) {
+                const uint2 a = ad[c];
+                y2o[c] = make_uint2(pack_bf16x2(o0 + bf16_to_f32((uint16_t)(a.x & 0xffffu)), o1 + bf16_to_f32((uint16_t)(a.x >> 16))),
+                                    pack_bf16x2(o2 + bf16_to_f32((uint16_t)(a.y & 0xffffu)), o3 + bf16_to_f32((uint16_t)(a.y >> 16))));
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -214,8 +246,17 @@ extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, co
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 2048, CCV_ESHAPE, "ccv_layernorm: C=%d must be a multiple of 64 and <= 2048", C);
     CCV_REQUIRE((addend == nullptr) == (y2 == nullptr), CCV_EINVAL, "ccv_layernorm: addend and y2 go together");
     CCV_REQUIRE(!addend || addend_rows > 0, CCV_EINVAL, "ccv_layernorm: addend_rows must be positive");
-    hipLaunchKernelGGL(ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, gamma, beta,
-                       rows, C, eps, addend, addend_rows > 0 ? addend_rows : 1, y2);
+    const dim3 grid((rows + 15) / 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ar = addend_rows > 0 ? addend_rows : 1;
+    if (C <= 320)
+        hipLaunchKernelGGL(ln_kernel<5>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+    else if (C <= 640)
+        hipLaunchKernelGGL(ln_kernel<10>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+    else if (C <= 1280)
+        hipLaunchKernelGGL(ln_kernel<20>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+    else
+        hipLaunchKernelGGL(ln_kernel<32>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     CCV_LAUNCH_CHECK("ccv_layernorm");
     return CCV_OK;
 }

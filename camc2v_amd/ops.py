@@ -106,7 +106,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
 # ---------------------------------------------------------------------------------------
 def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_str=None, scale=None,
               k2=None, v2=None, k2_str=None, v2_str=None, Lk2=0, gate2=1.0,
-              mask_bits=None, mask_nb=1, tile_flags=None, kreg=None, vreg=None, variant=None):
+              mask_bits=None, mask_nb=1, tile_flags=None, kreg=None, vreg=None, variant=None, perm=None):
     """Fused attention, head dim 64.  *_str = (batch_outer, batch_inner, token) strides in elements;
     q/k/v are bf16 tensors whose data_ptr() is the element (batch 0, token 0, head 0, d 0).
     Returns bf16 [B*Lq, H*64] unless `out`/`o_str` are given."""
@@ -143,6 +143,8 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
             p.flags_bs = tile_flags.shape[-2] * tile_flags.shape[-1]
     if kreg is not None:
         p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
+    if perm is not None:   # (frame tokens, frame width): rows and mask are in 4x8-patch order
+        p.perm_hw, p.perm_w = perm
     p.variant = ATTN_VARIANT if variant is None else variant
     check(lib().ccv_attn_fwd(C.byref(p), _stream()), "ccv_attn_fwd")
     return out
@@ -273,8 +275,14 @@ def ddim_cfg_step(x, e_c, e_uc, noise, coef, scale, guidance_rescale, want_x0=Tr
     return x_prev, x0
 
 
-def pack_mask(mask):
-    """bool [B, Lq, Lk] -> (bits int32 [B, Lq, ceil(Lk/32)], flags uint8 [B, ceil(Lq/128), ceil(Lk/64)])."""
+def patch_order_ok(H, W):
+    """4x8-pixel patch order is defined for feature maps with H % 4 == 0 and W % 8 == 0."""
+    return H % 4 == 0 and W % 8 == 0
+
+
+def pack_mask(mask, perm=None):
+    """bool [B, Lq, Lk] -> (bits int32 [B, Lq, ceil(Lk/32)], flags uint8 [B, ceil(Lq/128), ceil(Lk/64)]).
+    perm = (frame tokens, frame width) emits rows and bit columns in 4x8-patch order (see include/ccv.h)."""
     _dev(mask)
     if mask.dtype != torch.bool or mask.dim() != 3:
         raise CcvError("pack_mask: bool [B, Lq, Lk] expected")
@@ -282,11 +290,12 @@ def pack_mask(mask):
     B, Lq, Lk = mask.shape
     bits = torch.empty((B, Lq, (Lk + 31) // 32), dtype=torch.int32, device=mask.device)
     flags = torch.zeros((B, (Lq + 127) // 128, (Lk + 63) // 64), dtype=torch.uint8, device=mask.device)
-    check(lib().ccv_pack_mask(_ptr(mask), _ptr(bits), _ptr(flags), B, Lq, Lk, _stream()), "ccv_pack_mask")
+    hw, w = perm if perm is not None else (0, 0)
+    check(lib().ccv_pack_mask(_ptr(mask), _ptr(bits), _ptr(flags), B, Lq, Lk, hw, w, _stream()), "ccv_pack_mask")
     return bits, flags
 
 
-def epipolar_mask_bits(F, T, H, W, downsample):
+def epipolar_mask_bits(F, T, H, W, downsample, patch_order=False):
     """F [B, T, T, 3, 3] fp32 -> packed epipolar mask (bits, flags) for an HxW feature map."""
     _dev(F)
     F = F.contiguous().float()
@@ -294,6 +303,6 @@ def epipolar_mask_bits(F, T, H, W, downsample):
     L = T * H * W
     bits = torch.empty((B, L, (L + 31) // 32), dtype=torch.int32, device=F.device)
     flags = torch.zeros((B, (L + 127) // 128, (L + 63) // 64), dtype=torch.uint8, device=F.device)
-    check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), B, T, H, W, downsample, _stream()),
+    check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), B, T, H, W, downsample, int(patch_order), _stream()),
           "ccv_epipolar_mask_bits")
     return bits, flags

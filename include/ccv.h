@@ -134,6 +134,9 @@ typedef struct CcvAttn {
     int32_t mask_nb;  /* masks exist for mask_nb batches; batch i uses mask i % mask_nb (CFG halves share) */
     const uint8_t* tile_flags; int64_t flags_bs; int32_t flags_ktiles;
     const uint16_t* kreg; const uint16_t* vreg; int32_t nreg;
+    int32_t perm_hw, perm_w; /* token order of q/k/v/o rows and of the mask: 0 = as stored; otherwise the kernel walks each
+                              * frame (perm_hw tokens, perm_w wide) in 4x8-pixel patches (index -> row map in ccv_patch_row);
+                              * the mask must have been built with the same values */
     int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; two-context calls use kernel 1);
                          1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging */
 } CcvAttn;
@@ -207,11 +210,15 @@ int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* e_uc, const
  * [B, Lq, words] + tile flags [B, ceil(Lq/128), ceil(Lk/64)] (flags must be zeroed by caller).
  * ccv_epipolar_mask_bits: the same packed form straight from the fundamental matrices
  * F [B, T, T, 3, 3] (model/camcontexti2v.py:200-239), never materialising the bool tensor.
+ * Patch order (perm_hw = H*W, perm_w = W, needs H % 4 == 0 and W % 8 == 0): rows and bit columns are emitted in the
+ * order frame -> 4x8-pixel patch -> pixel, so that a 32-query x 32-key MFMA block covers two compact patches; an
+ * epipolar line then crosses ~28 % of the blocks instead of ~42 % in raster order (32x32 latents).  Attention
+ * calls using such a mask pass the same perm_hw / perm_w and read/write q, k, v, o rows through the same map.
  * ------------------------------------------------------------------------------------ */
 int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags,
-                  int32_t B, int32_t Lq, int32_t Lk, void* stream);
+                  int32_t B, int32_t Lq, int32_t Lk, int32_t perm_hw, int32_t perm_w, void* stream);
 int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags,
-                           int32_t B, int32_t T, int32_t H, int32_t W, int32_t downsample, void* stream);
+                           int32_t B, int32_t T, int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream);
 
 #ifdef __cplusplus
 }

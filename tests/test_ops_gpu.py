@@ -309,6 +309,50 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
     assert torch.equal(out, out2)
 
 
+def test_attention_patch_order(ops):
+    """4x8-patch token order: q/k/v/o rows stay in raster order in memory, the kernel walks them patch by patch and
+    the mask is packed in the same order; the result must equal raster-order masked attention."""
+    B, H, T, fh, fw, nreg = 2, 2, 6, 8, 16, 4
+    hw = fh * fw
+    L = T * hw
+    C = H * 64
+    g = torch.Generator().manual_seed(95)
+    mask = (torch.rand(1, L, L, generator=g) < 0.08).to(dev())
+    qkv = rnd(B * L, 3 * C, seed=96)
+    kreg, vreg = rnd(nreg, C, seed=97), rnd(nreg, C, seed=98)
+    ld = 3 * C
+    st = (L * ld, 0, ld)
+    outs = []
+    for perm in (None, (hw, fw)):
+        bits, flags = ops.pack_mask(mask, perm)
+        outs.append(ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st,
+                                  mask_bits=bits, mask_nb=1, tile_flags=flags, kreg=kreg, vreg=vreg, perm=perm))
+    x = qkv.float().reshape(B, L, 3, H, 64)
+    k = torch.cat([kreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)
+    v = torch.cat([vreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 2]], 1)
+    m = F.pad(mask.expand(B, -1, -1), (nreg, 0), value=True)
+    ref = ref_attn(x[:, :, 0], k, v, m)
+    assert_close(outs[0].reshape(B, L, H, 64), ref, 1.5e-2, "raster order")
+    assert_close(outs[1].reshape(B, L, H, 64), ref, 1.5e-2, "patch order")
+    # unmasked self attention is order independent too
+    o_r = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st)
+    o_p = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st, perm=(hw, fw))
+    assert_close(o_p, o_r, 1e-2, "dense patch order")
+
+
+def test_epipolar_mask_bits_patch_order(ops, golden_dir):
+    """Native patch-order mask == pack_mask(perm) of the same mask in raster order (both built on the GPU)."""
+    fx = np.load(os.path.join(golden_dir, "geometry.npz"))
+    Fm = torch.from_numpy(fx["F64"]).to(dev())
+    H = W = 8                                    # 64 px / d=8
+    bits_r, _ = ops.epipolar_mask_bits(Fm, 16, H, W, 8)
+    L = 16 * H * W
+    raster = torch.from_numpy(np.unpackbits(bits_r.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[..., :L].astype(bool)).to(dev())
+    bits_p, flags_p = ops.epipolar_mask_bits(Fm, 16, H, W, 8, patch_order=True)
+    ref_bits, ref_flags = ops.pack_mask(raster, (H * W, W))
+    assert torch.equal(bits_p, ref_bits) and torch.equal(flags_p, ref_flags)
+
+
 def test_attention_softmax_rescale_spike(ops):
     """Force the online-softmax rescale: one key tile carries a huge score late in the sequence."""
     B, H, Lq, Lk = 1, 1, 64, 512
