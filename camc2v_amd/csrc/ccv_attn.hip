@@ -274,13 +274,29 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 __device__ __attribute__((aligned(16))) unsigned char g_attn_zero_line[16];
 
+// 1-D grid -> (query block, head, batch) with an XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs,
+// so giving XCD x the contiguous range [x*n/8, (x+1)*n/8) of (batch, head, query block) makes the workgroups that
+// share an L2 walk the SAME (batch, head) K/V slice (4 MB at 32x32 latents = one XCD's L2) instead of eight
+// different ones that evict each other to the Infinity Cache.  Bijective for any grid size; speed only.
+__device__ __forceinline__ void attn_block_coords(int nq, int H, int& qblk, int& head, int& b) {
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    qblk = bid % nq;
+    const int t = bid / nq;
+    head = t % H;
+    b = t / H;
+}
+
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y, qblk = blockIdx.x;
+    int qblk, head, b;
+    attn_block_coords((p.Lq + 255) / 256, p.H, qblk, head, b);
     const long bo = b / p.inner, bi = b % p.inner;
     const int q0 = qblk * 256 + wave * 64;
     const bool wave_active = q0 < p.Lq;
@@ -361,6 +377,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                 }
             }
     };
+
+    // retire the Q-fragment loads where hipcc can see it (see attn_sparse_kernel): otherwise every use of qf in the
+    // loop is preceded by s_waitcnt vmcnt(0), which waits for the NEXT tile's DMA and serialises the ring
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) asm volatile("" ::"v"(qf[qb][s4]));
 
     int cur = next_tile(0), stage = 0;
     uint32_t mwc[2][2], mwn[2][2];
@@ -516,6 +539,260 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 
 
 // =================================================================================================
+// attn_sparse_kernel: masked (epipolar) attention where only 15-20 % of the 32x32 score blocks hold a
+// visible key.  Sharing 64-key tiles between the four waves of a workgroup (attn2_kernel<true>) makes every
+// wave pay the DMA, the barriers and the slowest wave of every tile that ANY of them needs; here each wave
+// is on its own: it owns 64 queries, walks the bitmap of 32-key blocks its query group needs (wave_bits,
+// built once per clip next to the mask), DMAs just those K/V blocks into a wave-private 2-deep LDS ring and
+// never meets a barrier.  Math per block is attn2's: S^T = K Q^T, in-lane softmax, O^T += V^T P^T.
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words
+    unsigned char* smw = sm + 4 * 2 * 8192;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    int qblk, head, b;
+    attn_block_coords((p.Lq + 255) / 256, p.H, qblk, head, b);
+    const long bo = b / p.inner, bi = b % p.inner;
+    const int q0 = qblk * 256 + wave * 64;
+    if (q0 >= p.Lq) return;  // no workgroup barriers in this kernel
+
+    bf16x8 qf[2][4];
+    int qi[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = min(q0 + 32 * qb + r, p.Lq - 1);
+        const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)ccv_patch_row(qi[qb], p.perm_hw, p.perm_w) * p.q_ls + head * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    const float sl2 = p.scale * 1.4426950408889634f;
+    const int mb = b % p.mask_nb;
+    const uint32_t* wrow = p.wave_bits + (long)mb * p.wave_bs + (long)(q0 >> 6) * p.wave_words;
+    const uint16_t* kmain = p.k + bo * p.k_bso + bi * p.k_bsi + head * 64;
+    const uint16_t* vmain = p.v + bo * p.v_bso + bi * p.v_bsi + head * 64;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
+    unsigned char* ring = sm + wave * 16384;
+    unsigned char* mwring = smw + wave * 512;   // [stage][64 words]
+    constexpr int DONE = 0x7fffffff;
+    const bool has_reg = p.kreg != nullptr && p.nreg > 0;
+
+    // ---- block schedule: -1 = register tokens, then the set bits of this query group's bitmap row ----
+    // The whole bitmap row (<= 64 words) is fetched once, one word per lane, and read back with v_readlane:
+    // an ordinary vector load inside the loop would make hipcc drain vmcnt(0), i.e. every DMA in flight.
+    const uint32_t my_word = (lane < p.wave_words) ? wrow[lane] : 0u;
+    int widx = -1;
+    uint32_t cbits = 0;
+    bool reg_pending = has_reg;
+    auto next_block = [&]() -> int {
+        if (reg_pending) { reg_pending = false; return -1; }
+        while (cbits == 0) {
+            if (++widx >= p.wave_words) return DONE;
+            cbits = (uint32_t)__builtin_amdgcn_readlane((int)my_word, widx);
+        }
+        const int bit = __builtin_ctz(cbits);
+        cbits &= cbits - 1;
+        return widx * 32 + bit;
+    };
+    // per-lane DMA source offsets (elements) of the 4 K and 4 V pieces of a 32-key block; a block is either 32
+    // consecutive stored rows (raster) or one 4x8-pixel patch: row 8j + (lane>>3) of the block is stored row
+    // base + j*W + (lane>>3), with `base` wave-uniform
+    const int lr8 = lane >> 3, pc = lane & 7;
+    long koff[4], voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rowin = 8 * j + lr8;
+        const long step = p.perm_w ? (long)j * p.perm_w + lr8 : (long)rowin;
+        koff[j] = step * p.k_ls + ((pc ^ ((rowin >> 1) & 7)) << 3);
+        voff[j] = step * p.v_ls + ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
+    }
+    auto issue = [&](int blk, int stage) {   // 8 K/V DMA pieces + 1 mask-word DMA = 9 vector-memory operations
+        unsigned char* sK = ring + stage * 8192;
+        unsigned char* sV = sK + 4096;
+        if (blk < 0) {   // register tokens: rows >= nreg read the zero line
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rowin = 8 * j + lr8;
+                const bool ok = rowin < p.nreg;
+                const uint16_t* gk = ok ? p.kreg + (long)rowin * p.H * 64 + head * 64 + ((pc ^ ((rowin >> 1) & 7)) << 3) : zero;
+                const uint16_t* gv = ok ? p.vreg + (long)rowin * p.H * 64 + head * 64 + ((pc ^ (((rowin >> 1) & 1) << 2)) << 3) : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t*)gk, (lptr_t*)(sK + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t*)gv, (lptr_t*)(sV + j * 1024), 16, 0, 0);
+            }
+        } else {
+            const int k0 = 32 * blk;
+            int base = k0;
+            if (p.perm_w) {   // first stored row of the patch (wave-uniform scalar arithmetic)
+                const int f = k0 / p.perm_hw, rem = k0 - f * p.perm_hw;
+                const int patch = rem >> 5, ppr = p.perm_w >> 3;
+                const int py = patch / ppr, px = patch - py * ppr;
+                base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
+            }
+            const uint16_t* kp = kmain + (long)base * p.k_ls;
+            const uint16_t* vp = vmain + (long)base * p.v_ls;
+            const bool full = k0 + 32 <= p.Lk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = full || (k0 + 8 * j + lr8) < p.Lk;
+                __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? kp + koff[j] : zero), (lptr_t*)(sK + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? vp + voff[j] : zero), (lptr_t*)(sV + j * 1024), 16, 0, 0);
+            }
+        }
+        // mask words of the 64 queries (lane l <-> query q0 + l) go to LDS by DMA as well: 4 bytes per lane
+        const int wi = blk < 0 ? 0 : blk;
+        const uint32_t* mp = p.mask_bits + (long)mb * p.mask_bs + (long)min(q0 + lane, p.Lq - 1) * p.mask_words + wi;
+        __builtin_amdgcn_global_load_lds((gptr_t*)mp, (lptr_t*)(mwring + stage * 256), 4, 0, 0);
+    };
+
+    float m_run[2] = {NEG_INF, NEG_INF}, l_run[2] = {0.f, 0.f};
+    f32x16 oacc[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int blk, int stage) {
+        const unsigned char* sK = ring + stage * 8192;
+        const unsigned char* sV = sK + 4096;
+        const int left = blk < 0 ? p.nreg : min(32, p.Lk - 32 * blk);
+        const uint32_t lim = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        const uint32_t* wl = reinterpret_cast<const uint32_t*>(mwring + stage * 256);
+        uint32_t mw[2];
+        mw[0] = (blk < 0 ? 0xffffffffu : wl[r]) & lim;
+        mw[1] = (blk < 0 ? 0xffffffffu : wl[32 + r]) & lim;
+        const bool on0 = __ballot(mw[0] != 0u) != 0ull;
+        const bool on1 = (q0 + 32 < p.Lq) && (__ballot(mw[1] != 0u) != 0ull);
+        if (!(on0 || on1)) return;
+        f32x16 sa0 = zero16, sa1 = zero16;
+        if (on0 && on1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = 2 * s + hh;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
+                sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = 2 * s + hh;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                if (on0) sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
+                else     sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
+            }
+        }
+        bf16x8 pf0[2], pf1[2];
+        auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
+            float tmax = NEG_INF;
+            if (__builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu))) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sa[i]);
+            } else {
+                const uint32_t wsh = w >> (4 * hh);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float sv = ((wsh >> ((i & 3) + 8 * (i >> 2))) & 1u) ? sa[i] : NEG_INF;
+                    sa[i] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+            const float m_new = fmaxf(m_r, tmax);
+            const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+            if (!__all(m_new == m_r)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
+                l_r *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oa[d][i] *= alpha;
+                m_r = m_new;
+            }
+            float psum = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[i], sl2, -m_use));
+                psum += pv[i];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pfo[s2][j] = (__bf16)pv[8 * s2 + j];
+            l_r += psum;
+        };
+        if (on0) softmax_block(sa0, mw[0], m_run[0], l_run[0], oacc[0], pf0);
+        if (on1) softmax_block(sa1, mw[1], m_run[1], l_run[1], oacc[1], pf1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kb0 = 16 * s2 + 4 * hh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int li = lane & 15, g = (lane >> 4) & 1;
+                const int row0 = kb0 + (li >> 2);
+                const int colb = (32 * d + 16 * g + 4 * (li & 3)) * 2;
+                const unsigned char* a0 = sV + row0 * 128 + (colb ^ (((row0 >> 1) & 1) << 6));
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * 128));
+                bf16x8 vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                if (on0) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0[s2], oacc[0][d], 0, 0, 0);
+                if (on1) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1[s2], oacc[1][d], 0, 0, 0);
+            }
+        }
+    };
+
+    // Retire every ordinary vector load (Q fragments, bitmap row) where hipcc can see it: its waitcnt bookkeeping
+    // cannot see the counted waits below, and a load it still believes pending inside the loop becomes an
+    // s_waitcnt vmcnt(0) in front of every use, i.e. it would drain the DMA ring on every MFMA.
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) asm volatile("" ::"v"(qf[qb][s4]));
+    asm volatile("" ::"v"(my_word));
+
+    // ---- two-deep software pipeline: the DMA of the next needed block flies while the current one is multiplied ----
+    int cur = next_block(), stage = 0;
+    if (cur != DONE) issue(cur, 0);
+    while (cur != DONE) {
+        const int nxt = next_block();
+        if (nxt != DONE) {
+            issue(nxt, stage ^ 1);
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // the 9 operations of `nxt` may stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        compute(cur, stage);
+        cur = nxt;
+        stage ^= 1;
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        const int q = q0 + 32 * qb + r;
+        if (q < p.Lq) {
+            uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)ccv_patch_row(q, p.perm_hw, p.perm_w) * p.o_ls + head * 64;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = 32 * d + 8 * g4 + 4 * hh;
+                    uint2 pk = make_uint2(pack_bf16x2(oacc[qb][d][4 * g4] * wgt, oacc[qb][d][4 * g4 + 1] * wgt),
+                                          pack_bf16x2(oacc[qb][d][4 * g4 + 2] * wgt, oacc[qb][d][4 * g4 + 3] * wgt));
+                    *reinterpret_cast<uint2*>(op + dd) = pk;
+                }
+        }
+    }
+}
+
+// =================================================================================================
 // attn_temporal_kernel: self attention over <= 16 tokens (the frames of one pixel), one wave per
 // (pixel, head).  HBM/L2-bound: Q and K fragments are loaded straight from the token-major activations
 // (16 rows x 64 B per instruction), S^T = K Q^T is two v_mfma_f32_16x16x32_bf16, the softmax runs on the
@@ -612,6 +889,8 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(!p.mask_bits || p.mask_words * 32 >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: mask_words too small");
     CCV_REQUIRE(!p.mask_bits || p.mask_nb > 0, CCV_EINVAL, "ccv_attn_fwd: mask_nb must be positive");
     CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
+    CCV_REQUIRE(!p.wave_bits || (p.mask_bits && (long)p.wave_words * 32 * 32 >= p.Lk), CCV_EINVAL,
+                "ccv_attn_fwd: wave_bits needs mask_bits and wave_words covering Lk");
     CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
     CCV_REQUIRE(p.nreg <= KT, CCV_ESHAPE, "ccv_attn_fwd: at most 64 register tokens");
     CCV_REQUIRE(p.perm_w == 0 || (p.variant == 0 && !p.k2 && p.perm_w % 8 == 0 && p.perm_hw > 0 && p.perm_hw % (4 * p.perm_w) == 0 &&
@@ -627,8 +906,12 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
         const long items = (long)p.B * p.H;
         hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
     } else if (p.variant == 0 && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
-        dim3 grid2((p.Lq + 255) / 256, p.H, p.B);
-        if (p.mask_bits)
+        const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
+        CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
+        dim3 grid2((unsigned)nwg2);
+        if (p.mask_bits && p.wave_bits)
+            hipLaunchKernelGGL(attn_sparse_kernel, grid2, dim3(256), 0, st, p);
+        else if (p.mask_bits)
             hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL(attn2_kernel<false>, grid2, dim3(256), 0, st, p);

@@ -170,7 +170,13 @@ __global__ void ddim_update_kernel(const float* x, const float* e_c, const float
 
 // ---- epipolar mask preparation -----------------------------------------------------------
 // bool bytes [B, Lq, Lk] -> words [B, Lq, W]; one thread per word (32 contiguous bytes).
-__global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* flags, int Lq, int Lk, int words,
+__device__ __forceinline__ void mark_block(uint32_t* wave_bits, int64_t b, int Lq, int q, int w, int words) {
+    // 64-query group (q / 64) needs key block w (32 keys)
+    const int wave_words = (words + 31) / 32;
+    atomicOr(wave_bits + (b * ((Lq + 63) / 64) + q / 64) * wave_words + (w >> 5), 1u << (w & 31));
+}
+
+__global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int Lq, int Lk, int words,
                                  int ktiles, int64_t nwords_total, int perm_hw, int perm_w) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords_total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -185,6 +191,7 @@ __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* f
             for (int j = 0; j < nk; ++j) word |= (srow[ccv_patch_row(w * 32 + j, perm_hw, perm_w)] ? 1u : 0u) << j;
             bits[i] = word;
             if (word && flags) flags[(b * ((Lq + 127) / 128) + q / 128) * ktiles + (w >> 1)] = 1;
+            if (word && wave_bits) mark_block(wave_bits, b, Lq, q, w, words);
             continue;
         }
         const uint8_t* src = mask + rowi * Lk + (int64_t)w * 32;
@@ -200,13 +207,14 @@ __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* f
         }
         bits[i] = word;
         if (word && flags) flags[(b * ((Lq + 127) / 128) + q / 128) * ktiles + (w >> 1)] = 1;
+        if (word && wave_bits) mark_block(wave_bits, b, Lq, q, w, words);
     }
 }
 
 // F [B, T, T, 3, 3] -> packed mask words; query (t1,p1) row, key (t2,p2) column.
 // Arithmetic mirrors model/camcontexti2v.py:229-239 in fp32 without FMA contraction:
 //   l = F x1; l /= ||l_xy||; visible <=> |l . x2| < d*sqrt(2)/2.
-__global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, int T, int H, int W, float d,
+__global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int T, int H, int W, float d,
                                      int words, int ktiles, int64_t nwords_total, int perm_w) {
 #pragma clang fp contract(off)
     const int HW = H * W, L = T * HW;
@@ -244,6 +252,7 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
         }
         bits[i] = word;
         if (word && flags) flags[(b * ((L + 127) / 128) + q / 128) * ktiles + (w >> 1)] = 1;
+        if (word && wave_bits) mark_block(wave_bits, b, L, q, w, words);
     }
 }
 
@@ -332,26 +341,26 @@ extern "C" int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* 
     return CCV_OK;
 }
 
-extern "C" int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, int32_t B, int32_t Lq, int32_t Lk,
-                             int32_t perm_hw, int32_t perm_w, void* stream) {
+extern "C" int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int32_t B, int32_t Lq,
+                             int32_t Lk, int32_t perm_hw, int32_t perm_w, void* stream) {
     CCV_REQUIRE(mask && bits && B > 0 && Lq > 0 && Lk > 0, CCV_EINVAL, "ccv_pack_mask: bad args");
     CCV_REQUIRE(perm_w == 0 || (perm_w % 8 == 0 && perm_hw > 0 && perm_hw % (4 * perm_w) == 0 && Lq % perm_hw == 0 && Lk % perm_hw == 0),
                 CCV_ESHAPE, "ccv_pack_mask: patch order needs W %% 8 == 0, H %% 4 == 0 and whole frames");
     const int words = (Lk + 31) / 32, ktiles = (Lk + 63) / 64;
     const int64_t n = (int64_t)B * Lq * words;
-    hipLaunchKernelGGL(pack_mask_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), mask, bits, flags, Lq, Lk, words, ktiles, n, perm_hw, perm_w);
+    hipLaunchKernelGGL(pack_mask_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), mask, bits, flags, wave_bits, Lq, Lk, words, ktiles, n, perm_hw, perm_w);
     CCV_LAUNCH_CHECK("ccv_pack_mask");
     return CCV_OK;
 }
 
-extern "C" int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, int32_t B, int32_t T, int32_t H,
-                                      int32_t W, int32_t downsample, int32_t patch_order, void* stream) {
+extern "C" int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int32_t B, int32_t T,
+                                      int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream) {
     CCV_REQUIRE(F && bits && B > 0 && T > 0 && H > 0 && W > 0 && downsample > 0, CCV_EINVAL, "ccv_epipolar_mask_bits: bad args");
     CCV_REQUIRE(!patch_order || (W % 8 == 0 && H % 4 == 0), CCV_ESHAPE, "ccv_epipolar_mask_bits: patch order needs W %% 8 == 0 and H %% 4 == 0");
     const int L = T * H * W;
     const int words = (L + 31) / 32, ktiles = (L + 63) / 64;
     const int64_t n = (int64_t)B * L * words;
-    hipLaunchKernelGGL(epipolar_bits_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), F, bits, flags, T, H, W,
+    hipLaunchKernelGGL(epipolar_bits_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), F, bits, flags, wave_bits, T, H, W,
                        (float)downsample, words, ktiles, n, patch_order ? W : 0);
     CCV_LAUNCH_CHECK("ccv_epipolar_mask_bits");
     return CCV_OK;

@@ -106,7 +106,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
 # ---------------------------------------------------------------------------------------
 def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_str=None, scale=None,
               k2=None, v2=None, k2_str=None, v2_str=None, Lk2=0, gate2=1.0,
-              mask_bits=None, mask_nb=1, tile_flags=None, kreg=None, vreg=None, variant=None, perm=None):
+              mask_bits=None, mask_nb=1, tile_flags=None, wave_bits=None, kreg=None, vreg=None, variant=None, perm=None):
     """Fused attention, head dim 64.  *_str = (batch_outer, batch_inner, token) strides in elements;
     q/k/v are bf16 tensors whose data_ptr() is the element (batch 0, token 0, head 0, d 0).
     Returns bf16 [B*Lq, H*64] unless `out`/`o_str` are given."""
@@ -141,6 +141,10 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
             p.tile_flags = _ptr(tile_flags)
             p.flags_ktiles = tile_flags.shape[-1]
             p.flags_bs = tile_flags.shape[-2] * tile_flags.shape[-1]
+        if wave_bits is not None:
+            p.wave_bits = _ptr(wave_bits)
+            p.wave_words = wave_bits.shape[-1]
+            p.wave_bs = wave_bits.shape[-2] * wave_bits.shape[-1]
     if kreg is not None:
         p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
     if perm is not None:   # (frame tokens, frame width): rows and mask are in 4x8-patch order
@@ -275,6 +279,16 @@ def ddim_cfg_step(x, e_c, e_uc, noise, coef, scale, guidance_rescale, want_x0=Tr
     return x_prev, x0
 
 
+class MaskPack(tuple):
+    """(bits, flags) with the per-64-query-group key-block bitmap riding along as ``.wave_bits``; unpacks as a pair
+    so existing ``bits, flags = pack_mask(...)`` call sites keep working."""
+
+    def __new__(cls, bits, flags, wave_bits):
+        self = super().__new__(cls, (bits, flags))
+        self.wave_bits = wave_bits
+        return self
+
+
 def patch_order_ok(H, W):
     """4x8-pixel patch order is defined for feature maps with H % 4 == 0 and W % 8 == 0."""
     return H % 4 == 0 and W % 8 == 0
@@ -290,9 +304,10 @@ def pack_mask(mask, perm=None):
     B, Lq, Lk = mask.shape
     bits = torch.empty((B, Lq, (Lk + 31) // 32), dtype=torch.int32, device=mask.device)
     flags = torch.zeros((B, (Lq + 127) // 128, (Lk + 63) // 64), dtype=torch.uint8, device=mask.device)
+    wbits = torch.zeros((B, (Lq + 63) // 64, ((Lk + 31) // 32 + 31) // 32), dtype=torch.int32, device=mask.device)
     hw, w = perm if perm is not None else (0, 0)
-    check(lib().ccv_pack_mask(_ptr(mask), _ptr(bits), _ptr(flags), B, Lq, Lk, hw, w, _stream()), "ccv_pack_mask")
-    return bits, flags
+    check(lib().ccv_pack_mask(_ptr(mask), _ptr(bits), _ptr(flags), _ptr(wbits), B, Lq, Lk, hw, w, _stream()), "ccv_pack_mask")
+    return MaskPack(bits, flags, wbits)
 
 
 def epipolar_mask_bits(F, T, H, W, downsample, patch_order=False):
@@ -303,6 +318,7 @@ def epipolar_mask_bits(F, T, H, W, downsample, patch_order=False):
     L = T * H * W
     bits = torch.empty((B, L, (L + 31) // 32), dtype=torch.int32, device=F.device)
     flags = torch.zeros((B, (L + 127) // 128, (L + 63) // 64), dtype=torch.uint8, device=F.device)
-    check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), B, T, H, W, downsample, int(patch_order), _stream()),
-          "ccv_epipolar_mask_bits")
-    return bits, flags
+    wbits = torch.zeros((B, (L + 63) // 64, ((L + 31) // 32 + 31) // 32), dtype=torch.int32, device=F.device)
+    check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), _ptr(wbits), B, T, H, W, downsample, int(patch_order),
+                                       _stream()), "ccv_epipolar_mask_bits")
+    return MaskPack(bits, flags, wbits)

@@ -288,12 +288,12 @@ class Epipolar(nn.Module, _Prepared):
         s = (L * ld, 0, ld)
         kw = {}
         if packed_mask is not None and not self.is_3d_full_attn:
-            bits, flags, nb, perm = packed_mask
+            bits, flags, nb, perm, wbits = packed_mask
             if bits.shape[1] != L:
                 raise CcvError(f"epipolar mask has {bits.shape[1]} query rows, feature map has {L} tokens")
             if perm is not None and perm != (g.h * g.w, g.w):
                 raise CcvError(f"epipolar mask was packed for frames {perm}, feature map is {g.h}x{g.w}")
-            kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm)
+            kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm, wave_bits=wbits)
         o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
                           kreg=pk.get("kreg"), vreg=pk.get("vreg"), scale=self.epipolar_attn.scale, **kw)
         ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
@@ -837,7 +837,8 @@ class UNetModel(nn.Module, _Prepared):
         masks = {}
         packed = camera_condition.get("sample_locs_packed")
         if packed is not None:
-            masks = {k: (v[0], v[1], v[0].shape[0], v[2] if len(v) > 2 else None) for k, v in packed.items()}
+            masks = {k: (v[0], v[1], v[0].shape[0], v[2] if len(v) > 2 else None, v[3] if len(v) > 3 else getattr(v, "wave_bits", None))
+                     for k, v in packed.items()}
         elif camera_condition.get("sample_locs_dict") is not None:
             origin_h = getattr(self, "epipolar_origin_h", 8 * H)
             for k, m in camera_condition["sample_locs_dict"].items():
@@ -845,8 +846,8 @@ class UNetModel(nn.Module, _Prepared):
                 hh = origin_h // k
                 ww = (W * hh) // H if H else 0
                 perm = (hh * ww, ww) if (hh > 0 and ww > 0 and ops.patch_order_ok(hh, ww) and t * hh * ww == m.shape[1]) else None
-                bits, flags = self._inputs.get(("mask", perm), m, lambda m=m, perm=perm: ops.pack_mask(m, perm))
-                masks[k] = (bits, flags, m.shape[0], perm)
+                mp = self._inputs.get(("mask", perm), m, lambda m=m, perm=perm: ops.pack_mask(m, perm))
+                masks[k] = (mp[0], mp[1], m.shape[0], perm, mp.wave_bits)
         return dict(rows=rows, masks=masks, add_type=camera_condition.get("add_type"))
 
     # ---- forward ----------------------------------------------------------------------------------------

@@ -133,6 +133,8 @@ typedef struct CcvAttn {
     const uint32_t* mask_bits; int64_t mask_bs; int32_t mask_words;
     int32_t mask_nb;  /* masks exist for mask_nb batches; batch i uses mask i % mask_nb (CFG halves share) */
     const uint8_t* tile_flags; int64_t flags_bs; int32_t flags_ktiles;
+    const uint32_t* wave_bits; int64_t wave_bs; int32_t wave_words; /* NULL or [mask_nb, ceil(Lq/64), wave_words] uint32: bit j of
+                              * word w set => the 64-query group needs key block 32*(32w+j) .. +31 (any visible key) */
     const uint16_t* kreg; const uint16_t* vreg; int32_t nreg;
     int32_t perm_hw, perm_w; /* token order of q/k/v/o rows and of the mask: 0 = as stored; otherwise the kernel walks each
                               * frame (perm_hw tokens, perm_w wide) in 4x8-pixel patches (index -> row map in ccv_patch_row);
@@ -207,7 +209,8 @@ int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* e_uc, const
  * Epipolar mask preparation (once per clip).
  * ccv_pack_mask: bool mask [B, Lq, Lk] (1 byte per element, as handed over in
  * camera_condition["sample_locs_dict"], model/camcontexti2v.py:552) -> bit-packed rows
- * [B, Lq, words] + tile flags [B, ceil(Lq/128), ceil(Lk/64)] (flags must be zeroed by caller).
+ * [B, Lq, words] + tile flags [B, ceil(Lq/128), ceil(Lk/64)] + per-64-query-group key-block bitmaps
+ * wave_bits [B, ceil(Lq/64), ceil(ceil(Lk/32)/32)] (flags and wave_bits must be zeroed by the caller; either may be NULL).
  * ccv_epipolar_mask_bits: the same packed form straight from the fundamental matrices
  * F [B, T, T, 3, 3] (model/camcontexti2v.py:200-239), never materialising the bool tensor.
  * Patch order (perm_hw = H*W, perm_w = W, needs H % 4 == 0 and W % 8 == 0): rows and bit columns are emitted in the
@@ -215,9 +218,9 @@ int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* e_uc, const
  * epipolar line then crosses ~28 % of the blocks instead of ~42 % in raster order (32x32 latents).  Attention
  * calls using such a mask pass the same perm_hw / perm_w and read/write q, k, v, o rows through the same map.
  * ------------------------------------------------------------------------------------ */
-int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags,
+int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
                   int32_t B, int32_t Lq, int32_t Lk, int32_t perm_hw, int32_t perm_w, void* stream);
-int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags,
+int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
                            int32_t B, int32_t T, int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream);
 
 #ifdef __cplusplus

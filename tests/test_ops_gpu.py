@@ -290,7 +290,8 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
         mask[:, :128, 64:192] = False                                   # an empty 128x128 region
         mask[:, 5] = False                                              # a row that only sees the registers
     mask = mask.to(dev())
-    bits, flags = ops.pack_mask(mask)
+    mp = ops.pack_mask(mask)
+    bits, flags = mp
     qkv = rnd(B * L, 3 * C, seed=31)
     kreg, vreg = rnd(nreg, C, seed=32), rnd(nreg, C, seed=33)
     ld = 3 * C
@@ -307,6 +308,19 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
                          k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1,
                          kreg=kreg, vreg=vreg, variant=variant)
     assert torch.equal(out, out2)
+    # per-wave sparse kernel (block bitmap from the packer): same math, different schedule
+    out3 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=(L * ld, 0, ld),
+                         k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1, tile_flags=flags,
+                         wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, variant=variant)
+    assert_close(out3.reshape(B, L, H, 64), ref_attn(x[:, :, 0], k, v, m), 1.5e-2, f"sparse kernel L={L}")
+    wb = mp.wave_bits.cpu().numpy().view(np.uint32)
+    need = mask[0].reshape(-1, L).cpu()
+    nq, nk = (L + 63) // 64, (L + 31) // 32
+    ref_need = torch.zeros(nq * 64, nk * 32, dtype=torch.bool)
+    ref_need[:L, :L] = need
+    ref_need = ref_need.reshape(nq, 64, nk, 32).any(3).any(1)
+    got_need = np.unpackbits(wb.view(np.uint8), axis=-1, bitorder="little")[0, :, :nk].astype(bool)
+    assert np.array_equal(got_need, ref_need.numpy())
 
 
 def test_attention_patch_order(ops):
@@ -324,9 +338,13 @@ def test_attention_patch_order(ops):
     st = (L * ld, 0, ld)
     outs = []
     for perm in (None, (hw, fw)):
-        bits, flags = ops.pack_mask(mask, perm)
+        mp = ops.pack_mask(mask, perm)
+        bits, flags = mp
         outs.append(ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st,
                                   mask_bits=bits, mask_nb=1, tile_flags=flags, kreg=kreg, vreg=vreg, perm=perm))
+        o_sparse = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st,
+                                 mask_bits=bits, mask_nb=1, wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, perm=perm)
+        assert_close(o_sparse, outs[-1], 1e-2, f"sparse vs tiled, perm={perm}")
     x = qkv.float().reshape(B, L, 3, H, 64)
     k = torch.cat([kreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)
     v = torch.cat([vreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 2]], 1)

@@ -118,7 +118,8 @@ def bench_epi():
         hh = px // d
         if patch and not ops.patch_order_ok(hh, hh):
             continue
-        bits, flags = ops.epipolar_mask_bits(Fm, T, hh, hh, d, patch_order=patch)
+        mp = ops.epipolar_mask_bits(Fm, T, hh, hh, d, patch_order=patch)
+        bits, flags = mp
         perm = (hh * hh, hh) if patch else None
         L = bits.shape[1]
         C = H * 64
@@ -129,10 +130,12 @@ def bench_epi():
         ld = 3 * C
         s = (L * ld, 0, ld)
         us = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
-                                          mask_bits=bits, mask_nb=1, tile_flags=flags, kreg=kreg, vreg=vreg, perm=perm), iters=10)
+                                          mask_bits=bits, mask_nb=1, tile_flags=flags, wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, perm=perm), iters=10)
+        us_t = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
+                                            mask_bits=bits, mask_nb=1, tile_flags=flags, kreg=kreg, vreg=vreg, perm=perm), iters=10)
         us_d = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s),
                       iters=5)
-        print(f"  L={L:6d} H={H:2d} {'patch ' if patch else 'raster'}: masked {us:8.1f} us (dense-equivalent {4 * 2 * H * L * L * 64 / us / 1e6:7.1f} TF/s), "
+        print(f"  L={L:6d} H={H:2d} {'patch ' if patch else 'raster'}: sparse {us:8.1f} us, tiled {us_t:8.1f} us (dense-equivalent {4 * 2 * H * L * L * 64 / us / 1e6:7.1f} TF/s), "
               f"unmasked {us_d:8.1f} us ({4 * 2 * H * L * L * 64 / us_d / 1e6:7.1f} TF/s); "
               f"element density {dens:.3f}, 128x64 tile density {flags.float().mean().item():.3f}")
 
