@@ -490,21 +490,43 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Wide LDS-DMA variant: block tile 128 x 320, wave tile 64 x 160 (2 x 2 waves), 32-deep K slabs in a
-// 4-stage LDS ring (3 slabs of DMA in flight behind counted s_waitcnt vmcnt + raw s_barrier).
-// Why this shape: with 64 x 64 wave tiles the fragment reads alone need 128 B/clk of LDS per workgroup
-// (2 workgroups per CU = the whole 256 B/clk LDS port), so the loop is LDS-read bound at ~25 % of the MFMA
-// peak.  A 64 x 160 wave tile reads (64+160) rows per 40 MFMAs: 22 B/clk per wave.  Every channel count of
-// the model is a multiple of 320, so N tiles exactly and M = 32768 gives 256 workgroups = one per CU.
+// Ring LDS-DMA variant: block tile (32 MT) x (32 NT) with 2 x 2 waves (wave tile 16 MT x 16 NT), 32-deep K
+// slabs in an ST-stage LDS ring: ST-1 slabs of DMA stay in flight behind counted s_waitcnt vmcnt + raw
+// s_barrier.  Instances: 128x320 / 64x320 / 128x160 / 64x160 -- every channel count of the model is a multiple
+// of 160, so N tiles exactly and the dispatcher can pick the shape whose tile count fills the 256 CUs evenly.
+// Why wide wave tiles: with 64 x 64 wave tiles the fragment reads alone need 128 B/clk of LDS per workgroup
+// (2 workgroups per CU = the whole LDS port), which bounds the loop at ~25 % of the MFMA peak; a 64 x 160 wave
+// tile reads (64+160) rows per 40 MFMAs.  Why the deep ring: the small-M layers (8x8 / 4x4 latents) are bound by
+// the global->LDS latency of each slab, not by bandwidth; with 3-7 slabs in flight it overlaps.
 // -------------------------------------------------------------------------------------------------
-constexpr int WIDE_BM = 128, WIDE_BN = 320, WIDE_BK = 32, WIDE_ST = 4;
-constexpr int WIDE_STAGE_BYTES = (WIDE_BM + WIDE_BN) * WIDE_BK * 2;  // 28 KiB
+constexpr int RING_BK = 32;
 
-template <int GATHER>
-__global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
-    constexpr int MT = 4, NT = 10;
-    constexpr int AI = 2, BI = 5;  // DMA wave-instructions per wave and slab (16 rows of 64 B each)
-    constexpr int PER_SLAB = AI + BI;
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// slab s must have landed; `younger` slabs (PER DMA instructions each per wave) may stay in flight
+template <int PER, int Y>
+struct WaitSlab {
+    static __device__ __forceinline__ void run(int younger) {
+        if (younger >= Y) wait_vm_barrier<PER * Y>();
+        else WaitSlab<PER, Y - 1>::run(younger);
+    }
+};
+template <int PER>
+struct WaitSlab<PER, 0> {
+    static __device__ __forceinline__ void run(int) { wait_vm_barrier<0>(); }
+};
+
+template <int MT, int NT, int ST, int GATHER>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(const CcvGemm p) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int AI = BM / 64;           // A pieces (16 rows of 64 B = one DMA wave-instruction) per wave and slab
+    constexpr int BP = BN / 16;           // B pieces per slab in total
+    constexpr int BI = (BP + 3) / 4;      // ... per wave; a wave without a piece of its own re-fetches the last one
+    constexpr int PER_SLAB = AI + BI;     //     (same bytes to the same LDS slot) so that vmcnt counts stay uniform
+    constexpr int STAGE_BYTES = (BM + BN) * RING_BK * 2;
+    static_assert((ST & (ST - 1)) == 0 && PER_SLAB * (ST - 2) <= 63, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -512,7 +534,7 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tiles_n = p.N / WIDE_BN;
+    const int tiles_n = p.N / BN;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
@@ -521,8 +543,8 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
     }
     const int split = (p.split_k > 1) ? bid % p.split_k : 0;
     if (p.split_k > 1) bid /= p.split_k;
-    const int m0 = (bid / tiles_n) * WIDE_BM;
-    const int n0 = (bid % tiles_n) * WIDE_BN;
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
 
     const int lrow = lane >> 2, lchunk = lane & 3;
     int a_base[AI], a_y[AI], a_x[AI], a_col[AI];
@@ -548,17 +570,19 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
         }
     }
     const int ldw = p.taps * p.K;
-    const int slabs_per_tap = p.K / WIDE_BK;
+    const int slabs_per_tap = p.K / RING_BK;
     const int nslab_all = p.taps * slabs_per_tap;
     const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
     const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
     const uint16_t* b_ptr[BI];
+    int b_piece[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-        const int r = 16 * (4 * j + wave) + lrow;
-        b_ptr[j] = p.W + (long)(n0 + r) * ldw + (long)s_begin * WIDE_BK + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
+        b_piece[j] = min(4 * j + wave, BP - 1);
+        const int r = 16 * b_piece[j] + lrow;
+        b_ptr[j] = p.W + (long)(n0 + r) * ldw + (long)s_begin * RING_BK + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
     }
     const uint16_t* a_ptr[AI];
     int a_step[AI];
@@ -581,12 +605,12 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
                 }
             }
             a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
-            a_step[j] = (src >= 0) ? WIDE_BK : 0;
+            a_step[j] = (src >= 0) ? RING_BK : 0;
         }
     };
     int tap_cur = s_begin / slabs_per_tap;
     int slab_in_tap = s_begin - tap_cur * slabs_per_tap;
-    set_tap(tap_cur, slab_in_tap * WIDE_BK);
+    set_tap(tap_cur, slab_in_tap * RING_BK);
 
     auto issue = [&](int stage) {  // DMA the next slab into ring slot `stage` (slabs are issued strictly in order)
         if (slab_in_tap == slabs_per_tap) {
@@ -594,8 +618,8 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
             ++tap_cur;
             set_tap(tap_cur, 0);
         }
-        unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
-        unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
+        unsigned char* sA = smem + stage * STAGE_BYTES;
+        unsigned char* sB = sA + BM * RING_BK * 2;
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
             __builtin_amdgcn_global_load_lds((gptr_t*)a_ptr[j], (lptr_t*)(sA + 16 * (4 * j + wave) * 64), 16, 0, 0);
@@ -603,8 +627,8 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
         }
 #pragma unroll
         for (int j = 0; j < BI; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t*)b_ptr[j], (lptr_t*)(sB + 16 * (4 * j + wave) * 64), 16, 0, 0);
-            b_ptr[j] += WIDE_BK;
+            __builtin_amdgcn_global_load_lds((gptr_t*)b_ptr[j], (lptr_t*)(sB + 16 * b_piece[j] * 64), 16, 0, 0);
+            b_ptr[j] += RING_BK;
         }
         ++slab_in_tap;
     };
@@ -616,31 +640,24 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
 
-    // prologue: three slabs in flight
+    // prologue: ST-1 slabs in flight
 #pragma unroll
-    for (int k = 0; k < WIDE_ST - 1; ++k)
+    for (int k = 0; k < ST - 1; ++k)
         if (s_begin + k < s_end) issue(k);
 
     for (int s = s_begin; s < s_end; ++s) {
-        const int stage = (s - s_begin) & (WIDE_ST - 1);
-        // slab s must have landed; up to two younger slabs may stay in flight (7 DMA instructions each per wave)
-        const int younger = min(WIDE_ST - 2, s_end - 1 - s);
-        if (younger >= 2)
-            asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
-        else if (younger == 1)
-            asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const int stage = (s - s_begin) & (ST - 1);
+        WaitSlab<PER_SLAB, ST - 2>::run(s_end - 1 - s);
         // the stage consumed in the previous iteration is free now: every wave passed the barrier after reading it
-        if (s + WIDE_ST - 1 < s_end) issue((stage + WIDE_ST - 1) & (WIDE_ST - 1));
-        const unsigned char* sA = smem + stage * WIDE_STAGE_BYTES;
-        const unsigned char* sB = sA + WIDE_BM * WIDE_BK * 2;
+        if (s + ST - 1 < s_end) issue((stage + ST - 1) & (ST - 1));
+        const unsigned char* sA = smem + stage * STAGE_BYTES;
+        const unsigned char* sB = sA + BM * RING_BK * 2;
         bf16x8 fa[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off<32>(wm * 64 + 16 * i + fr, fg));
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off<32>(wm * 16 * MT + 16 * i + fr, fg));
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sB + lds_off<32>(wn * 160 + 16 * j + fr, fg));
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sB + lds_off<32>(wn * 16 * NT + 16 * j + fr, fg));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
@@ -649,21 +666,21 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
 
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + fr;
+        const int m = m0 + wm * 16 * MT + 16 * i + fr;
         if (m >= p.M) continue;
         if (p.split_k > 1) {
             float* wsp = static_cast<float*>(p.ws) + ((long)split * p.M + m) * p.N;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * 160 + 16 * j + 4 * fg;
+                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
                 *reinterpret_cast<float4*>(wsp + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
             continue;
         }
-        if (p.geglu) {
+        if (NT % 2 == 0 && p.geglu) {
 #pragma unroll
-            for (int j = 0; j < NT; j += 2) {
-                const int n = n0 + wn * 160 + 16 * j + 4 * fg;
+            for (int j = 0; j + 1 < NT; j += 2) {
+                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
                 const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
                 epilogue_geglu(p, m, n, a_, g_);
@@ -672,7 +689,7 @@ __global__ __launch_bounds__(256) void gemm_dma_wide_kernel(const CcvGemm p) {
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wn * 160 + 16 * j + 4 * fg;
+            const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
             float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             epilogue_store(p, m, n, o);
         }
@@ -737,18 +754,18 @@ inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
     mt = 2; nt = 2;
 }
 
-// Split-K factor: long-K problems that cannot fill the chip with output tiles alone (the 4x4 / 8x8
-// latent layers stream 30-60 MB of weights through a few dozen workgroups otherwise).
+// Split-K factor for the 128x128-family kernels: long-K problems that cannot fill the chip with output tiles
+// alone (the 8x8 / 4x4 latent layers stream 10-60 MB of weights through a few dozen workgroups otherwise).
+// Fitted to tools/gemm_tune.py on MI355X: aim at ~2.5 workgroups per CU, keep >= 20 slabs of 64 per split, and
+// do not split when the fp32 partials (split * M * N * 4 bytes, written and re-read) outweigh the gain.
 inline int choose_split(const CcvGemm& p) {
     int mt, nt;
     choose_tile(p, mt, nt);
     const long tiles = (long)((p.M + 32 * mt - 1) / (32 * mt)) * ((p.N + 32 * nt - 1) / (32 * nt));
     const int nslab = p.taps * (p.K / BK);
-    // measured on MI355X: splitting pays when the grid is at most ~1 workgroup per CU, or up to ~2 per CU
-    // when K is very long (conv3x3 at 8x8 / 4x4 latents: 180-360 slabs); otherwise the reduce pass costs more
-    if (nslab < 16 || tiles >= 512 || (tiles > 256 && nslab < 64)) return 1;
-    long s = (1024 + tiles - 1) / tiles;
-    if (s > nslab / 8) s = nslab / 8;
+    if ((long)p.M * p.N > (4l << 20) || tiles >= 512) return 1;
+    long s = 640 / tiles;
+    if (s > nslab / 20) s = nslab / 20;
     if (s > 16) s = 16;
     return s < 2 ? 1 : (int)s;
 }
@@ -776,18 +793,19 @@ int launch_dma(const CcvGemm& p, hipStream_t st) {
     return CCV_OK;
 }
 
-template <int GATHER>
-int launch_wide(const CcvGemm& p, hipStream_t st) {
-    const int tiles = ((p.M + WIDE_BM - 1) / WIDE_BM) * (p.N / WIDE_BN) * (p.split_k > 1 ? p.split_k : 1);
-    const size_t lds = (size_t)WIDE_ST * WIDE_STAGE_BYTES;
-    auto kern = gemm_dma_wide_kernel<GATHER>;
+template <int MT, int NT, int ST, int GATHER>
+int launch_ring(const CcvGemm& p, hipStream_t st) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * (p.split_k > 1 ? p.split_k : 1);
+    const size_t lds = (size_t)ST * (BM + BN) * RING_BK * 2;
+    auto kern = gemm_ring_kernel<MT, NT, ST, GATHER>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
-    CCV_LAUNCH_CHECK("ccv_gemm(wide)");
+    CCV_LAUNCH_CHECK("ccv_gemm(ring)");
     if (p.split_k > 1) {
         const long total = (long)p.M * (p.N / 4);
         long blocks = (total + 255) / 256;
@@ -798,15 +816,72 @@ int launch_wide(const CcvGemm& p, hipStream_t st) {
     return CCV_OK;
 }
 
-// the wide tile applies when N tiles exactly by 320 and the grid fills most of the chip
-inline bool wide_applies(const CcvGemm& p) {
-    static const bool enabled = [] { const char* e = getenv("CCV_GEMM_WIDE"); return !(e && e[0] == '0'); }();
-    if (!enabled || p.a_f32 || p.N % WIDE_BN != 0 || p.split_k > 1) return false;
-    const long tiles = (long)((p.M + WIDE_BM - 1) / WIDE_BM) * (p.N / WIDE_BN);
-    // measured on MI355X: wins on long-K problems (conv3x3 at 32x32 latents: 650-690 vs 600-620 TFLOP/s for the
-    // 128x128 tile); short-K problems (K = 320..1280 linears) are bound by the fp32 stream traffic of their
-    // epilogue, where the 1-workgroup-per-CU wide tile hides less latency than two 128x128 workgroups
-    return tiles >= 192 && (long)p.taps * p.K >= 2048;
+// ---- kernel selection -----------------------------------------------------------------------------------
+// ring configurations: block tile and ring depth
+struct RingCfg { int bm, bn, st; };
+constexpr int N_RING = 5;
+const RingCfg kRing[N_RING] = {
+    {128, 320, 4},   // 112 KiB LDS, 1 workgroup per CU
+    {64, 320, 4},    //  96 KiB
+    {128, 160, 4},   //  72 KiB, 2 per CU
+    {64, 160, 4},    //  56 KiB, 2 per CU
+    {64, 160, 8},    // 112 KiB
+};
+
+struct Plan {
+    int ring;    // index into kRing, or -1: 128x128-family kernels (gemm_dma_kernel / gemm_kernel)
+    int split;   // split-K factor (1 = none)
+};
+
+inline int tune_env(const char* name) {  // CCV_GEMM_TUNE=1 re-reads the tuning variables on every call (probe tools)
+    static const bool live = [] { const char* e = getenv("CCV_GEMM_TUNE"); return e && e[0] == '1'; }();
+    if (!live) return -2;
+    const char* e = getenv(name);
+    return e ? atoi(e) : -2;
+}
+
+inline bool ring_fits(const CcvGemm& p, int r) {
+    const RingCfg& c = kRing[r];
+    if (p.a_f32 || p.N % c.bn != 0 || p.K % RING_BK != 0) return false;
+    if (p.geglu && (c.bn / 32) % 2 != 0) return false;   // the GEGLU epilogue pairs 16-column groups inside a wave tile
+    return true;
+}
+
+// Which kernel runs a problem.  Fitted to the sweep of tools/gemm_tune.py on MI355X (profiles/r01_gemm_tune.txt):
+//  * linear layers (taps == 1): the 128x128 family (64-deep slabs, 2 workgroups per CU) wins or ties everywhere;
+//  * 3x3 / temporal convolutions: the 128x160 ring tile when its tile count fills the chip (with split-K to reach
+//    256-512 workgroups on the 16x16 .. 4x4 latent layers), the 128x320 tile for the longest K at 8x8 latents,
+//    the 128x128 family for long K at 32x32 latents where both tie and it needs no workspace.
+inline Plan make_plan(const CcvGemm& p, bool allow_split) {
+    static const bool ring_on = [] { const char* e = getenv("CCV_GEMM_WIDE"); return !(e && e[0] == '0'); }();
+    const int forced_ring = tune_env("CCV_GEMM_RING"), forced_split = tune_env("CCV_GEMM_SPLIT");
+    const int nslab = p.taps * (p.K / RING_BK);
+    auto family = [&]() {   // 128x128-family kernels: 64-deep slabs, every split needs at least two of them
+        Plan pl{-1, 1};
+        if (!allow_split) return pl;
+        if (forced_split <= 0) { pl.split = choose_split(p); return pl; }
+        const int cap = p.taps * (p.K / BK) / 2;
+        pl.split = forced_split > cap ? (cap < 1 ? 1 : cap) : forced_split;
+        return pl;
+    };
+    auto ring = [&](int r, int sp) {   // ring tile r with split sp, clamped to >= 16 slabs per workgroup
+        if (forced_split > 0) sp = forced_split;
+        if (!allow_split) sp = 1;
+        if (sp > nslab / 16) sp = nslab / 16;
+        if (sp > 16) sp = 16;
+        return Plan{r, sp < 1 ? 1 : sp};
+    };
+    if (forced_ring == -1 || !ring_on || p.a_f32) return family();
+    if (forced_ring >= 0) return ring_fits(p, forced_ring) ? ring(forced_ring, forced_split > 0 ? forced_split : 1) : family();
+    if (p.taps == 1 || !ring_fits(p, 2)) return family();
+    const long tiles2 = (long)((p.M + 127) / 128) * (p.N / 160);   // 128x160 tiles
+    if (p.taps == 3) return tiles2 >= 512 ? ring(2, 1) : family();
+    if (tiles2 >= 512) return nslab <= 100 ? ring(2, 1) : family();
+    if (ring_fits(p, 0) && nslab >= 480 && tiles2 <= 128 && tiles2 >= 64) return ring(0, (int)(512 / tiles2));
+    int sp = (int)(256 / tiles2);
+    if (sp < 1) sp = 1;
+    if (tiles2 >= 256 && nslab / sp >= 180) sp *= 2;
+    return ring(2, sp);
 }
 
 inline bool dma_enabled() {  // CCV_GEMM_DMA=0 falls back to the register-staged loop (tuning aid)
@@ -819,11 +894,22 @@ inline int slab_depth_override() {  // CCV_GEMM_BK=32|64 forces the slab depth (
     return v;
 }
 
+template <int GATHER>
+int dispatch_ring(const CcvGemm& p, int ring, hipStream_t st) {
+    switch (ring) {
+        case 0: return launch_ring<4, 10, 4, GATHER>(p, st);
+        case 1: return launch_ring<2, 10, 4, GATHER>(p, st);
+        case 2: return launch_ring<4, 5, 4, GATHER>(p, st);
+        case 3: return launch_ring<2, 5, 4, GATHER>(p, st);
+        default: return launch_ring<2, 5, 8, GATHER>(p, st);
+    }
+}
+
 template <bool A_F32, int GATHER>
-int dispatch_tile(const CcvGemm& p, hipStream_t st) {
+int dispatch_tile(const CcvGemm& p, int ring, hipStream_t st) {
     int mt, nt;
     choose_tile(p, mt, nt);
-    if (!A_F32 && wide_applies(p)) return launch_wide<GATHER>(p, st);
+    if (!A_F32 && ring >= 0) return dispatch_ring<GATHER>(p, ring, st);
     if (!A_F32 && dma_enabled()) {
         if (mt == 4 && nt == 4) return launch_dma<4, 4, GATHER>(p, st);
         if (mt == 2 && nt == 4) return launch_dma<2, 4, GATHER>(p, st);
@@ -846,19 +932,36 @@ int dispatch_tile(const CcvGemm& p, hipStream_t st) {
 
 }  // namespace
 
+inline bool plan_ok(const CcvGemm& p) {
+    return p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0 && p.taps > 0;
+}
+
 extern "C" int64_t ccv_gemm_ws_bytes(const CcvGemm* pp) {
-    if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0 || pp->K % BK != 0 || pp->taps <= 0) return 0;
-    const int s = choose_split(*pp);
-    return s > 1 ? (int64_t)s * pp->M * pp->N * (int64_t)sizeof(float) : 0;
+    if (pp == nullptr || !plan_ok(*pp)) return 0;
+    const Plan pl = make_plan(*pp, true);
+    return pl.split > 1 ? (int64_t)pl.split * pp->M * pp->N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
+    CCV_REQUIRE(pp && tile && split, CCV_EINVAL, "ccv_gemm_plan: null pointer");
+    CCV_REQUIRE(plan_ok(*pp), CCV_ESHAPE, "ccv_gemm_plan: bad problem sizes");
+    const Plan pl = make_plan(*pp, true);
+    *tile = pl.ring;
+    *split = pl.split;
+    return CCV_OK;
 }
 
 extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_gemm: null params");
     CcvGemm p = *pp;
-    {   // split-K only when the caller provided the workspace ccv_gemm_ws_bytes() asks for
-        const int s = (p.K > 0 && p.K % BK == 0 && p.M > 0 && p.N > 0 && p.taps > 0) ? choose_split(p) : 1;
-        p.split_k = (s > 1 && p.ws != nullptr && p.ws_bytes >= (int64_t)s * p.M * p.N * (int64_t)sizeof(float)) ? s : 1;
+    Plan pl{-1, 1};
+    if (plan_ok(p)) {   // split-K only when the caller provided the workspace ccv_gemm_ws_bytes() asks for
+        pl = make_plan(p, true);
+        if (pl.split > 1 && !(p.ws != nullptr && p.ws_bytes >= (int64_t)pl.split * p.M * p.N * (int64_t)sizeof(float)))
+            pl = make_plan(p, false);
     }
+    p.split_k = pl.split;
+    const int ring = pl.ring;
     CCV_REQUIRE(p.A && p.W && p.C, CCV_EINVAL, "ccv_gemm: null A/W/C");
     CCV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, CCV_EINVAL, "ccv_gemm: non-positive M/N/K (%d,%d,%d)", p.M, p.N, p.K);
     CCV_REQUIRE(p.K % BK == 0, CCV_ESHAPE, "ccv_gemm: K=%d must be a multiple of 64", p.K);
@@ -874,18 +977,18 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     switch (p.gather) {
         case 0:
             CCV_REQUIRE(p.taps == 1, CCV_EINVAL, "ccv_gemm: linear gather needs taps == 1");
-            return p.a_f32 ? dispatch_tile<true, 0>(p, st) : dispatch_tile<false, 0>(p, st);
+            return p.a_f32 ? dispatch_tile<true, 0>(p, ring, st) : dispatch_tile<false, 0>(p, ring, st);
         case 1:
             CCV_REQUIRE(p.taps == 9, CCV_EINVAL, "ccv_gemm: conv3x3 gather needs taps == 9");
             CCV_REQUIRE(p.out_h > 0 && p.out_w > 0 && p.src_h > 0 && p.src_w > 0 && (p.stride == 1 || p.stride == 2) &&
                             (p.upsample == 0 || p.upsample == 1) && p.M % (p.out_h * p.out_w) == 0,
                         CCV_EINVAL, "ccv_gemm: bad conv geometry");
-            return p.a_f32 ? dispatch_tile<true, 1>(p, st) : dispatch_tile<false, 1>(p, st);
+            return p.a_f32 ? dispatch_tile<true, 1>(p, ring, st) : dispatch_tile<false, 1>(p, ring, st);
         case 2:
             CCV_REQUIRE(p.taps == 3, CCV_EINVAL, "ccv_gemm: tconv3 gather needs taps == 3");
             CCV_REQUIRE(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0, CCV_EINVAL, "ccv_gemm: bad tconv geometry");
             CCV_REQUIRE(!p.a_f32, CCV_ESHAPE, "ccv_gemm: tconv3 takes bf16 activations");
-            return dispatch_tile<false, 2>(p, st);
+            return dispatch_tile<false, 2>(p, ring, st);
         default:
             ccv_set_error("ccv_gemm: unknown gather %d", p.gather);
             return CCV_EINVAL;

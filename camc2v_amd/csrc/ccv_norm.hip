@@ -14,22 +14,24 @@
 namespace {
 
 constexpr int GN_GROUPS = 32;
-constexpr int GN_MAX_CHUNKS = 256;
+constexpr int GN_MAX_CHUNKS = 128;
+constexpr int GN_UNROLL = 8;       // rows a thread has in flight per batch (memory-level parallelism)
 
-// chunks per instance: aim at ~1024 workgroups in total, at least ~8 rows per chunk
-inline int gn_chunks(int instances, int rows) {
-    int c = (1024 + instances - 1) / instances;
-    const int by_rows = (rows + 7) / 8;
-    if (c > by_rows) c = by_rows;
-    if (c > GN_MAX_CHUNKS) c = GN_MAX_CHUNKS;
-    return c < 1 ? 1 : c;
-}
-// threads per block: a multiple of C/4 (each thread owns 4 fixed channels), <= 1024, ~256 when possible
+// threads per block: a multiple of C/4 (each thread owns 4 fixed channels), <= 1024, >= 256
 inline int gn_threads(int C) {
     const int cols = C / 4;
     int r = (256 + cols - 1) / cols;   // at least 256 threads (the statistics prologue uses 256)
     if (r < 1) r = 1;
     return cols * r;
+}
+// chunks per instance: aim at ~1024 workgroups in total, at least one full batch of rows per thread
+inline int gn_chunks(int instances, int rows, int C) {
+    const int R = gn_threads(C) / (C / 4);
+    int c = (1024 + instances - 1) / instances;
+    const int by_rows = (rows + GN_UNROLL * R - 1) / (GN_UNROLL * R);
+    if (c > by_rows) c = by_rows;
+    if (c > GN_MAX_CHUNKS) c = GN_MAX_CHUNKS;
+    return c < 1 ? 1 : c;
 }
 
 template <bool X_F32>
@@ -40,82 +42,75 @@ __device__ __forceinline__ float4 load4(const void* x, long idx4) {
                        bf16_to_f32((uint16_t)(u.y & 0xffffu)), bf16_to_f32((uint16_t)(u.y >> 16)));
 }
 
-// grid (nchunk, instances), 256 threads.  A wave reads 64 consecutive float4 columns of one row (1 KiB,
-// coalesced); the 4 waves take every 4th row of the chunk.  A lane's columns are fixed (lane + 64*cb), so
-// its partial sums belong to fixed channel pairs; the block then reduces across waves and across the
-// pairs of each group in a FIXED order (no atomics: results are bitwise reproducible).
-constexpr int GN_MAXCB = 16;  // C/4 <= 64 * 16  =>  C <= 4096
-
+// grid (nchunk, instances), gn_threads(C) threads.  Thread (roff, col) owns the 4 channels of float4 column
+// `col` on rows r0+roff, r0+roff+R, ...; GN_UNROLL row loads are issued back to back before any is consumed
+// (the pass is latency-bound otherwise: a chunk is only a few dozen rows).  Its partial sums belong to two
+// fixed channel pairs; the block reduces over roff and over the pairs of each group in a FIXED order.
 template <bool X_F32>
-__global__ __launch_bounds__(256) void gn_stats(const void* x, float* partial, int rows_per_instance, int C) {
-    extern __shared__ __attribute__((aligned(16))) float gsm[];  // [4 waves][cols][4] then [cols*4]
+__global__ __launch_bounds__(1024) void gn_stats(const void* x, float* partial, int rows_per_instance, int C) {
+    __shared__ __attribute__((aligned(16))) float gsm[1024 * 4];  // [R][cols] x (sum01, sq01, sum23, sq23)
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int cols = C >> 2;
-    const int ncb = (cols + 63) >> 6;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = threadIdx.x % cols, roff = threadIdx.x / cols, R = blockDim.x / cols;
     const int rows_per_chunk = (rows_per_instance + nchunk - 1) / nchunk;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(rows_per_instance, r0 + rows_per_chunk);
-    float acc[GN_MAXCB][4];
+    const long base = (long)inst * rows_per_instance * cols + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int r = r0 + roff; r < r1; r += GN_UNROLL * R) {
+        float4 v[GN_UNROLL];
 #pragma unroll
-    for (int cb = 0; cb < GN_MAXCB; ++cb) acc[cb][0] = acc[cb][1] = acc[cb][2] = acc[cb][3] = 0.f;
-    const long base = (long)inst * rows_per_instance * cols;
-    for (int r = r0 + wave; r < r1; r += 4) {
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int rr = r + u * R;
+            v[u] = (rr < r1) ? load4<X_F32>(x, base + (long)rr * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-        for (int cb = 0; cb < GN_MAXCB; ++cb) {
-            const int col = lane + 64 * cb;
-            if (cb < ncb && col < cols) {
-                const float4 v = load4<X_F32>(x, base + (long)r * cols + col);
-                acc[cb][0] += v.x + v.y; acc[cb][1] += v.x * v.x + v.y * v.y;
-                acc[cb][2] += v.z + v.w; acc[cb][3] += v.z * v.z + v.w * v.w;
-            }
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            a0 += v[u].x + v[u].y; a1 += v[u].x * v[u].x + v[u].y * v[u].y;
+            a2 += v[u].z + v[u].w; a3 += v[u].z * v[u].z + v[u].w * v[u].w;
         }
     }
-#pragma unroll
-    for (int cb = 0; cb < GN_MAXCB; ++cb) {
-        const int col = lane + 64 * cb;
-        if (cb < ncb && col < cols)
-            *reinterpret_cast<float4*>(gsm + ((long)wave * cols + col) * 4) = make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]);
-    }
-    __syncthreads();
-    float* flat = gsm + 4 * cols * 4;  // [pairs][2] = (sum, sumsq) per channel pair
-    for (int i = threadIdx.x; i < cols * 4; i += 256)
-        flat[i] = (gsm[i] + gsm[cols * 4 + i]) + (gsm[2 * cols * 4 + i] + gsm[3 * cols * 4 + i]);
+    *reinterpret_cast<float4*>(gsm + (roff * cols + col) * 4) = make_float4(a0, a1, a2, a3);
     __syncthreads();
     if (threadIdx.x < GN_GROUPS * 2) {
         const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
         const int ppg = (C / GN_GROUPS) >> 1;  // channel pairs per group (channels per group is even)
         float a = 0.f;
-        for (int i = 0; i < ppg; ++i) a += flat[(g * ppg + i) * 2 + k];
+        for (int i = 0; i < ppg; ++i) {
+            const int pr = g * ppg + i;        // pair -> float4 column pr/2, half pr&1
+            float t = 0.f;
+            for (int ro = 0; ro < R; ++ro) t += gsm[(ro * cols + (pr >> 1)) * 4 + (pr & 1) * 2 + k];
+            a += t;
+        }
         partial[((long)inst * nchunk + chunk) * GN_GROUPS * 2 + threadIdx.x] = a;
     }
 }
 
-// grid (nchunk, instances), 256..1024 threads.  Prologue: the block reduces the chunk partials of its instance to
-// (mean, rstd) per group in a fixed order (8 threads per group + shuffles; every block of an instance computes
-// the same bits), which saves a separate finalize launch per GroupNorm; then y = (x-mean)*rstd*gamma+beta [SiLU].
+// grid (nchunk, instances), gn_threads(C) threads.  Prologue: the block reduces the chunk partials of its
+// instance to (mean, rstd) per group in a fixed order (4 threads per (group, moment), all loads of a thread in
+// flight together; every block of an instance computes the same bits), which saves a separate finalize launch
+// per GroupNorm; then y = (x-mean)*rstd*gamma+beta [SiLU], GN_UNROLL/2 rows in flight per thread.
 template <bool X_F32>
 __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, const float* gamma, const float* beta,
                                                  const float* partial, int rows_per_instance, int C, int silu,
                                                  float inv_count, float eps) {
-    __shared__ float s_stat[GN_GROUPS * 2];
+    __shared__ float s_sum[GN_GROUPS * 2];
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     if (threadIdx.x < 256) {
-        const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
-        float a = 0.f, b = 0.f;
-        for (int c = j; c < nchunk; c += 8) {
-            const float* pp = partial + (((long)inst * nchunk + c) * GN_GROUPS + g) * 2;
-            a += pp[0];
-            b += pp[1];
-        }
+        const int gk = threadIdx.x >> 2, j = threadIdx.x & 3;   // gk = 2*group + moment
+        const float* pp = partial + (long)inst * nchunk * GN_GROUPS * 2 + gk;
+        float v[GN_MAX_CHUNKS / 4];
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if (j == 0) {
-            const float mean = a * inv_count;
-            const float var = fmaxf(b * inv_count - mean * mean, 0.f);
-            s_stat[2 * g] = mean;
-            s_stat[2 * g + 1] = rsqrtf(var + eps);
+        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) {
+            const int c = j + 4 * i;
+            v[i] = (c < nchunk) ? pp[(long)c * GN_GROUPS * 2] : 0.f;
         }
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) a += v[i];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (j == 0) s_sum[gk] = a;
     }
     __syncthreads();
     const int cols = C >> 2;
@@ -128,17 +123,28 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = 4 * col + k, g = c / cpg;
-        sc[k] = s_stat[2 * g + 1] * gamma[c];
-        sh[k] = beta[c] - s_stat[2 * g] * sc[k];
+        const float mean = s_sum[2 * g] * inv_count;
+        const float var = fmaxf(s_sum[2 * g + 1] * inv_count - mean * mean, 0.f);
+        sc[k] = rsqrtf(var + eps) * gamma[c];
+        sh[k] = beta[c] - mean * sc[k];
     }
-    const long base = (long)inst * rows_per_instance * cols;
+    const long base = (long)inst * rows_per_instance * cols + col;
     uint2* yo = reinterpret_cast<uint2*>(y);
-    for (int r = r0 + roff; r < r1; r += R) {
-        const long idx = base + (long)r * cols + col;
-        const float4 v = load4<X_F32>(x, idx);
-        float o0 = v.x * sc[0] + sh[0], o1 = v.y * sc[1] + sh[1], o2 = v.z * sc[2] + sh[2], o3 = v.w * sc[3] + sh[3];
-        if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
-        yo[idx] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+    constexpr int U = GN_UNROLL / 2;
+    for (int r = r0 + roff; r < r1; r += U * R) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * R;
+            v[u] = (rr < r1) ? load4<X_F32>(x, base + (long)rr * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * R;
+            float o0 = v[u].x * sc[0] + sh[0], o1 = v[u].y * sc[1] + sh[1], o2 = v[u].z * sc[2] + sh[2], o3 = v[u].w * sc[3] + sh[3];
+            if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+            if (rr < r1) yo[base + (long)rr * cols] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        }
     }
 }
 
@@ -220,15 +226,14 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     CCV_REQUIRE(instances <= 65535, CCV_ESHAPE, "ccv_groupnorm: too many instances");
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm: C=%d must be a multiple of 64 and <= 4096", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nchunk = gn_chunks(instances, rows_per_instance);
+    const int nchunk = gn_chunks(instances, rows_per_instance, C);
     const int nthreads = gn_threads(C);
     float* partial = static_cast<float*>(ws);
     dim3 grid(nchunk, instances);
-    const size_t lds = (size_t)(C / 4) * 4 * sizeof(float) * 5;  // 4 per-wave slabs + the reduced row
     if (x_f32)
-        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(256), lds, st, x, partial, rows_per_instance, C);
+        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(nthreads), 0, st, x, partial, rows_per_instance, C);
     else
-        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(256), lds, st, x, partial, rows_per_instance, C);
+        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(nthreads), 0, st, x, partial, rows_per_instance, C);
     CCV_LAUNCH_CHECK("ccv_groupnorm(stats)");
     const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
     if (x_f32)

@@ -29,11 +29,12 @@ class DiffusionWrapper(nn.Module):
             return self.diffusion_model(x, t)
         if key == "concat":
             return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t, **kwargs)
+        # a single context tensor is handed over as is: the UNet caches its K/V projections by tensor identity
+        ctx = (lambda: c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(list(c_crossattn), 1))
         if key == "crossattn":
-            return self.diffusion_model(x, t, context=torch.cat(list(c_crossattn), 1), **kwargs)
+            return self.diffusion_model(x, t, context=ctx(), **kwargs)
         if key == "hybrid":
-            return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t,
-                                        context=torch.cat(list(c_crossattn), 1), **kwargs)
+            return self.diffusion_model(torch.cat([x] + list(c_concat), dim=1), t, context=ctx(), **kwargs)
         raise NotImplementedError(f"conditioning_key {key!r} is not used by the shipped configs")
 
 
@@ -94,7 +95,9 @@ class LatentDiffusionCore(nn.Module):
             return self.apply_model(x, t, c, **kwargs), self.apply_model(x, t, uc, **kwargs)
         b = x.shape[0]
         xc = torch.cat([torch.cat([x] + list(c["c_concat"]), 1), torch.cat([x] + list(uc["c_concat"]), 1)], 0)
-        ctx = [torch.cat(list(c["c_crossattn"]), 1), torch.cat(list(uc["c_crossattn"]), 1)]
+        # a single context tensor is handed over as is: the UNet caches its K/V projections by tensor identity
+        one = lambda parts: parts[0] if len(parts) == 1 else torch.cat(list(parts), 1)
+        ctx = [one(c["c_crossattn"]), one(uc["c_crossattn"])]
         extra = {k: v for k, v in c.items() if k not in ("c_concat", "c_crossattn")}
         kw = dict(kwargs)
         if kw.get("fs") is not None:

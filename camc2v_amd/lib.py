@@ -54,6 +54,7 @@ SIGNATURES = {
     "ccv_last_error": (C.c_char_p, []),
     "ccv_gemm": (i32, [C.POINTER(CcvGemm), vp]),
     "ccv_gemm_ws_bytes": (i64, [C.POINTER(CcvGemm)]),
+    "ccv_gemm_plan": (i32, [C.POINTER(CcvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
     "ccv_groupnorm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),

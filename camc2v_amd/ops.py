@@ -97,8 +97,18 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     if ws_bytes > 0:  # split-K workspace for long-K / few-tile problems
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         p.ws, p.ws_bytes = _ptr(ws), ws_bytes
+    global LAST_GEMM_PLAN
+    if TRACK_GEMM_PLAN:
+        tile, split = C.c_int32(0), C.c_int32(0)
+        check(lib().ccv_gemm_plan(C.byref(p), C.byref(tile), C.byref(split)), "ccv_gemm_plan")
+        LAST_GEMM_PLAN = (tile.value, split.value)
     check(lib().ccv_gemm(C.byref(p), _stream()), "ccv_gemm")
     return out
+
+
+# tests / tuning tools: when TRACK_GEMM_PLAN is set, LAST_GEMM_PLAN = (ring tile index or -1, split-K) of the last call
+TRACK_GEMM_PLAN = False
+LAST_GEMM_PLAN = None
 
 
 # ---------------------------------------------------------------------------------------

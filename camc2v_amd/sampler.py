@@ -125,6 +125,10 @@ class _GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.x_prev, self.pred_x0 = step()
+        # the capture read the UNet's step-invariant caches (context K/V, masks, Plucker rows): pin those tensors
+        unet = getattr(getattr(sampler.model, "model", None), "diffusion_model", None)
+        cached = getattr(unet, "_inputs", None)
+        self.keepalive += (list(cached.items.values()) if cached is not None else [],)
 
     def run(self, x, t_row, coef_row, noise):
         if x.data_ptr() != self.x_prev.data_ptr():

@@ -212,10 +212,15 @@ class FeedForward(nn.Module, _Prepared):
         w, b = pack.interleave_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
         return dict(w1=w, b1=b, w2=pack.pack_linear(self.net[2].weight), b2=_dev_f32(self.net[2].bias))
 
-    def run(self, n, stream):
+    def run(self, n, stream, final=False):
+        """final: the stream is only read as a GEMM operand afterwards (proj_out), so the sum is handed back
+        rounded to bf16 (the rounding the operand load would apply anyway) instead of updating the fp32 stream."""
         pk = self._pk()
         hidden = ops.gemm(n, pk["w1"], bias=pk["b1"], geglu=True)
+        if final:
+            return ops.gemm(hidden, pk["w2"], bias=pk["b2"], residual=stream)
         ops.gemm(hidden, pk["w2"], bias=pk["b2"], residual=stream, out_f32=True, out=stream)
+        return stream
 
     def forward(self, x):
         shp = x.shape
@@ -339,12 +344,12 @@ class BasicTransformerBlock(nn.Module, _Prepared):
         pk = self._pk()
         return ops.layernorm(stream, pk[f"g{i}"], pk[f"b{i}"], eps=getattr(self, f"norm{i}").eps, addend=addend)
 
-    def run_spatial(self, stream, g, ctx_groups):
+    def run_spatial(self, stream, g, ctx_groups, final=False):
         self.attn1.self_attn_spatial(self._ln(1, stream), stream, g)
         self.attn2.cross_attn(self._ln(2, stream), stream, g, ctx_groups)
-        self.ff.run(self._ln(3, stream), stream)
+        return self.ff.run(self._ln(3, stream), stream, final)
 
-    def run_temporal(self, stream, g, cam):
+    def run_temporal(self, stream, g, cam, final=False):
         """cam: None or dict(rows=bf16 Pluecker rows or None, mask=(bits, flags, nb) or None, add_type=str)."""
         patched = hasattr(self, "pluker_projection") or hasattr(self, "epipolar")
         if cam is None or not patched:
@@ -369,7 +374,7 @@ class BasicTransformerBlock(nn.Module, _Prepared):
                 _, nz = self._ln(1, stream, addend=ops.cast_bf16(target))
                 self.attn1.self_attn_temporal(nz, stream, g)
         self.attn2.self_attn_temporal(self._ln(2, stream), stream, g)
-        self.ff.run(self._ln(3, stream), stream)
+        return self.ff.run(self._ln(3, stream), stream, final)
 
 
 class SpatialTransformer(nn.Module, _Prepared):
@@ -402,8 +407,9 @@ class SpatialTransformer(nn.Module, _Prepared):
         pk = self._pk()
         n = ops.groupnorm(x, pk["gn_g"], pk["gn_b"], instances=g.b * g.t, eps=self.norm.eps, silu=False)
         s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_f32=True)
-        for blk, groups in zip(self.transformer_blocks, ctx_groups_per_block):
-            blk.run_spatial(s, g, groups)
+        last = len(self.transformer_blocks) - 1
+        for i, (blk, groups) in enumerate(zip(self.transformer_blocks, ctx_groups_per_block)):
+            s = blk.run_spatial(s, g, groups, final=(i == last))
         return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_f32=True)
 
 
@@ -438,8 +444,9 @@ class TemporalTransformer(nn.Module, _Prepared):
         pk = self._pk()
         n = ops.groupnorm(x, pk["gn_g"], pk["gn_b"], instances=g.b, eps=self.norm.eps, silu=False)
         s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_f32=True)
-        for blk in self.transformer_blocks:
-            blk.run_temporal(s, g, cam)
+        last = len(self.transformer_blocks) - 1
+        for i, blk in enumerate(self.transformer_blocks):
+            s = blk.run_temporal(s, g, cam, final=(i == last))
         return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_f32=True)
 
 

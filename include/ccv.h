@@ -96,6 +96,10 @@ typedef struct CcvGemm {
  * call still succeeds, unsplit. */
 int64_t ccv_gemm_ws_bytes(const CcvGemm* p);
 int ccv_gemm(const CcvGemm* p, void* stream);
+/* Which kernel ccv_gemm would run for this problem when the workspace is provided (introspection for tests and
+ * the tuning tools; no device work): *tile = index of the LDS-ring tile configuration (0: 128x320, 1: 64x320,
+ * 2: 128x160, 3: 64x160 4-deep, 4: 64x160 8-deep) or -1 for the 128x128-family kernels; *split = split-K factor. */
+int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
 
 /* ------------------------------------------------------------------------------------
  * ccv_attn_fwd: O = softmax(Q K^T * scale [+ mask]) V, head dim 64, bf16 MFMA, fp32 online

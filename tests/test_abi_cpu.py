@@ -65,3 +65,34 @@ def test_product_path_refuses_cpu_tensors(built):
     from camc2v_amd.lib import CcvError
     with pytest.raises(CcvError):
         ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+
+
+def _plan(built, M, N, K, taps=1, gather=0, geglu=0, a_f32=0):
+    p = built.CcvGemm()
+    p.M, p.N, p.K, p.taps, p.gather, p.geglu, p.a_f32 = M, N, K, taps, gather, geglu, a_f32
+    tile, split = ctypes.c_int32(-9), ctypes.c_int32(-9)
+    rc = built.lib().ccv_gemm_plan(ctypes.byref(p), ctypes.byref(tile), ctypes.byref(split))
+    assert rc == 0, built.lib().ccv_last_error()
+    ws = built.lib().ccv_gemm_ws_bytes(ctypes.byref(p))
+    assert ws == (split.value * M * N * 4 if split.value > 1 else 0)   # workspace request and plan agree
+    return tile.value, split.value
+
+
+def test_gemm_planner_host_logic(built):
+    """Kernel selection is host code (no device work): the model's layer classes map to the kernels the sweep
+    in profiles/ found fastest, and the workspace request always matches the planned split."""
+    assert _plan(built, 32768, 960, 320) == (-1, 1)                      # QKV projection: 128x128 family, unsplit
+    assert _plan(built, 32768, 2560, 320, geglu=1) == (-1, 1)
+    assert _plan(built, 2048, 1280, 5120) == (-1, 2)                     # FF down-projection at 8x8 latents
+    assert _plan(built, 32768, 320, 320, taps=9, gather=1) == (2, 1)     # conv3x3 at 32x32 latents: 128x160 ring tile
+    assert _plan(built, 32768, 320, 960, taps=9, gather=1) == (-1, 1)    # long K at 32x32: 128x128 family
+    assert _plan(built, 8192, 640, 640, taps=9, gather=1) == (2, 2)
+    assert _plan(built, 2048, 1280, 2560, taps=9, gather=1) == (0, 4)    # longest K at 8x8: 128x320 tile, split 4
+    assert _plan(built, 512, 1280, 1280, taps=9, gather=1) == (2, 8)     # 4x4 latents: 32 tiles x 8 splits
+    assert _plan(built, 32768, 320, 320, taps=3, gather=2) == (2, 1)
+    assert _plan(built, 2048, 1280, 1280, taps=3, gather=2) == (-1, 2)
+    assert _plan(built, 32768, 512, 2048) == (-1, 1)                     # N not a multiple of 160: never a ring tile
+    assert _plan(built, 2048, 1280, 2560, a_f32=1)[0] == -1              # fp32 activations: register-staged kernel
+    p = built.CcvGemm()
+    tile, split = ctypes.c_int32(0), ctypes.c_int32(0)
+    assert built.lib().ccv_gemm_plan(ctypes.byref(p), ctypes.byref(tile), ctypes.byref(split)) != 0

@@ -198,6 +198,45 @@ def test_gemm_wide_tile_paths(ops):
     assert_close(out.reshape(b, t, hw, 320).permute(0, 3, 1, 2), reft[..., 0], 2e-3, "wide tconv3")
 
 
+@pytest.mark.parametrize("ring,split", [(0, 1), (0, 2), (1, 1), (1, 3), (2, 1), (2, 4), (3, 1), (3, 2), (4, 1), (4, 2)])
+def test_gemm_ring_configs(ops, ring, split, monkeypatch):
+    """Every LDS-ring tile configuration (128x320, 64x320, 128x160, 64x160 with a 4- and 8-deep ring), unsplit and
+    split-K, forced through the tuning variables: ragged-M linear with residual, GEGLU, conv3x3 with padding,
+    temporal conv; each against the fp32 torch reference of the same op."""
+    from camc2v_amd.pack import interleave_geglu, pack_conv3x3, pack_tconv3
+    monkeypatch.setenv("CCV_GEMM_RING", str(ring))
+    monkeypatch.setenv("CCV_GEMM_SPLIT", str(split))
+    monkeypatch.setattr(ops, "TRACK_GEMM_PLAN", True)
+    M, N, K = 1024 + 40, 640, 2048
+    a, w = rnd(M, K, seed=180), rnd(N, K, seed=181, scale=0.02)
+    bias, res = rnd(N, seed=182, dtype=torch.float32), rnd(M, N, seed=183, dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    assert_close(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref + res, 2e-3, "ring linear + residual")
+    assert ops.LAST_GEMM_PLAN == (ring, split)
+    assert_close(ops.gemm(a, w, bias=bias, act=ops.ACT_SILU), F.silu(ref), 1e-2, "ring linear + SiLU, bf16 out")
+    if ring in (0, 1):   # GEGLU pairs 16-column groups inside a wave tile: 320-wide tiles only
+        wg, bg = rnd(640, K, seed=185, scale=0.02), rnd(640, seed=186, dtype=torch.float32)
+        wp, bp = interleave_geglu(wg, bg)
+        val, gate = (a.float() @ wg.float().t() + bg).chunk(2, dim=-1)
+        assert_close(ops.gemm(a, wp, bias=bp, geglu=True), val * F.gelu(gate), 1.5e-2, "ring geglu")
+        assert ops.LAST_GEMM_PLAN == (ring, split)
+    n, cin, cout, hs = 6, 256, 320, 12
+    x = rnd(n, cin, hs, hs, seed=187, dtype=torch.float32).to(torch.bfloat16).float()
+    wt = rnd(cout, cin, 3, 3, seed=188, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    cb = rnd(cout, seed=189, dtype=torch.float32)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, bias=cb, gather=ops.GATHER_CONV3X3, conv=(hs, hs, hs, hs, 1, 0), out_f32=True)
+    assert ops.LAST_GEMM_PLAN == (ring, split)
+    assert_close(out.reshape(n, hs, hs, cout).permute(0, 3, 1, 2), F.conv2d(x, wt, cb, padding=1), 2e-3, "ring conv3x3")
+    b, c, t, hw = 2, 512, 8, 36
+    xt = rnd(b, c, t, hw, 1, seed=191, dtype=torch.float32).to(torch.bfloat16).float()
+    wtt = rnd(320, c, 3, 1, 1, seed=192, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    rows = xt[..., 0].permute(0, 2, 3, 1).reshape(-1, c).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_tconv3(wtt), k=c, taps=3, gather=ops.GATHER_TCONV3, tconv=(t, hw), out_f32=True)
+    assert ops.LAST_GEMM_PLAN == (ring, min(split, 3))   # 48 slabs of 32: at most 3 splits of >= 16
+    assert_close(out.reshape(b, t, hw, 320).permute(0, 3, 1, 2), F.conv3d(xt, wtt, None, padding=(1, 0, 0))[..., 0], 2e-3, "ring tconv3")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from camc2v_amd.lib import CcvError
     with pytest.raises(CcvError):
