@@ -43,7 +43,8 @@ def pairwise_fundamental(K, rel_c2w, perturb_zero_translation=True, generator=No
 
 
 def epipolar_masks_packed(F, T, H_px, W_px, attention_resolution=(8, 4, 2, 1), patch_order=True):
-    """F [b,T,T,3,3] -> {8*ds: (bits int32 [b, L, L/32], flags uint8 [b, L/128, L/64], perm, wave_bits int32 [b, L/64, L/1024])},
+    """F [b,T,T,3,3] -> {8*ds: (bits int32 [b, L, L/32], flags uint8 [b, L/128, L/64], perm, wave_bits int32 [b, L/64, L/1024],
+    group_order int32 [b, L/64])},
     L = T*(H_px/8ds)*(W_px/8ds).
     perm = (H*W, W) when the mask is emitted in 4x8-patch token order (feature maps with H % 4 == 0, W % 8 == 0;
     fewer non-empty 32x32 attention blocks), else None (raster order)."""
@@ -53,7 +54,7 @@ def epipolar_masks_packed(F, T, H_px, W_px, attention_resolution=(8, 4, 2, 1), p
         H, W = H_px // d, W_px // d
         po = bool(patch_order and ops.patch_order_ok(H, W))
         mp = ops.epipolar_mask_bits(F, T, H, W, d, patch_order=po)
-        out[d] = (mp[0], mp[1], (H * W, W) if po else None, mp.wave_bits)
+        out[d] = (mp[0], mp[1], (H * W, W) if po else None, mp.wave_bits, mp.group_order)
     return out
 
 

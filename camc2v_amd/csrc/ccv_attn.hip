@@ -546,17 +546,45 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 // built once per clip next to the mask), DMAs just those K/V blocks into a wave-private 2-deep LDS ring and
 // never meets a barrier.  Math per block is attn2's: S^T = K Q^T, in-lane softmax, O^T += V^T P^T.
 // =================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p) {
+// Work distribution: a 64-query group costs between ~0.5x and ~1.4x the average (its bitmap popcount), and the
+// 2560 groups of the 32x32-latent layers do not divide over the 2048 resident waves, so a static grid ends with
+// half-empty CUs waiting for the last workgroups (measured: 47 % average wave occupancy).  The kernel is therefore
+// persistent: every wave pulls the next item from a counter, and the items are ordered longest first
+// (p.group_order, built with the mask): item i = (rank i / BH, batch-head i % BH).  In a simulation of the
+// benchmark mask this brings the makespan from 1.79x to 1.34x the ideal (total work / resident waves).
+__device__ unsigned int g_sparse_ctr[64];
+
+__global__ void sparse_ctr_reset(int slot) {
+    if (threadIdx.x == 0) g_sparse_ctr[slot] = 0u;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, int slot) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words
     unsigned char* smw = sm + 4 * 2 * 8192;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    int qblk, head, b;
-    attn_block_coords((p.Lq + 255) / 256, p.H, qblk, head, b);
+    const float sl2 = p.scale * 1.4426950408889634f;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
+    unsigned char* ring = sm + wave * 16384;
+    unsigned char* mwring = smw + wave * 512;   // [stage][64 words]
+    constexpr int DONE = 0x7fffffff;
+    const bool has_reg = p.kreg != nullptr && p.nreg > 0;
+    const int ngroups = (p.Lq + 63) >> 6;
+    const long total = (long)p.B * p.H * ngroups;
+    const int nbh = p.B * p.H;
+
+  for (;;) {
+    unsigned int idx = 0;
+    if (lane == 0) idx = atomicAdd(&g_sparse_ctr[slot], 1u);
+    const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
+    if (item >= total) break;
+    const int rank = (int)(item / nbh);
+    const int bh = (int)(item % nbh);
+    const int head = bh % p.H, b = bh / p.H;
+    const int qg = p.group_order ? p.group_order[(long)(b % p.mask_nb) * p.order_bs + rank] : rank;
     const long bo = b / p.inner, bi = b % p.inner;
-    const int q0 = qblk * 256 + wave * 64;
-    if (q0 >= p.Lq) return;  // no workgroup barriers in this kernel
+    const int q0 = qg * 64;
 
     bf16x8 qf[2][4];
     int qi[2];
@@ -567,16 +595,10 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
-    const float sl2 = p.scale * 1.4426950408889634f;
     const int mb = b % p.mask_nb;
-    const uint32_t* wrow = p.wave_bits + (long)mb * p.wave_bs + (long)(q0 >> 6) * p.wave_words;
+    const uint32_t* wrow = p.wave_bits + (long)mb * p.wave_bs + (long)qg * p.wave_words;
     const uint16_t* kmain = p.k + bo * p.k_bso + bi * p.k_bsi + head * 64;
     const uint16_t* vmain = p.v + bo * p.v_bso + bi * p.v_bsi + head * 64;
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
-    unsigned char* ring = sm + wave * 16384;
-    unsigned char* mwring = smw + wave * 512;   // [stage][64 words]
-    constexpr int DONE = 0x7fffffff;
-    const bool has_reg = p.kreg != nullptr && p.nreg > 0;
 
     // ---- block schedule: -1 = register tokens, then the set bits of this query group's bitmap row ----
     // The whole bitmap row (<= 64 words) is fetched once, one word per lane, and read back with v_readlane:
@@ -790,6 +812,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p) {
                 }
         }
     }
+  }  // next query group
 }
 
 // =================================================================================================
@@ -889,28 +912,41 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(!p.mask_bits || p.mask_words * 32 >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: mask_words too small");
     CCV_REQUIRE(!p.mask_bits || p.mask_nb > 0, CCV_EINVAL, "ccv_attn_fwd: mask_nb must be positive");
     CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
+    CCV_REQUIRE(p.variant != 3 || (p.wave_bits && !p.k2), CCV_EINVAL, "ccv_attn_fwd: variant 3 needs wave_bits and a single context");
     CCV_REQUIRE(!p.wave_bits || (p.mask_bits && (long)p.wave_words * 32 * 32 >= p.Lk), CCV_EINVAL,
                 "ccv_attn_fwd: wave_bits needs mask_bits and wave_words covering Lk");
     CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
     CCV_REQUIRE(p.nreg <= KT, CCV_ESHAPE, "ccv_attn_fwd: at most 64 register tokens");
-    CCV_REQUIRE(p.perm_w == 0 || (p.variant == 0 && !p.k2 && p.perm_w % 8 == 0 && p.perm_hw > 0 && p.perm_hw % (4 * p.perm_w) == 0 &&
+    CCV_REQUIRE(p.perm_w == 0 || ((p.variant == 0 || p.variant == 3) && !p.k2 && p.perm_w % 8 == 0 && p.perm_hw > 0 && p.perm_hw % (4 * p.perm_w) == 0 &&
                                   p.Lq % p.perm_hw == 0 && p.Lk % p.perm_hw == 0),
                 CCV_ESHAPE, "ccv_attn_fwd: patch order needs the single-context kernel, W %% 8 == 0, H %% 4 == 0 and whole frames");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gridDim.z is limited to 65535: fold large batches (temporal attention: one batch per pixel)
-    const bool temporal_path = p.variant == 0 && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16 && p.perm_w == 0;
+    const bool temporal_path = (p.variant == 0 || p.variant == 3) && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16 && p.perm_w == 0;
     CCV_REQUIRE(temporal_path || p.B <= 65535, CCV_ESHAPE, "ccv_attn_fwd: B=%d exceeds 65535 (split the call)", p.B);
     dim3 grid((p.Lq + 127) / 128, p.H, p.B);
     if (temporal_path) {
         // frames-of-a-pixel attention: one wave per (batch, head), no key tiling
         const long items = (long)p.B * p.H;
         hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
-    } else if (p.variant == 0 && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
+    } else if ((p.variant == 0 || p.variant == 3) && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
         const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
         CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
         dim3 grid2((unsigned)nwg2);
-        if (p.mask_bits && p.wave_bits)
-            hipLaunchKernelGGL(attn_sparse_kernel, grid2, dim3(256), 0, st, p);
+        if (p.mask_bits && p.wave_bits && (p.variant == 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024)) {
+            // persistent: 2 workgroups per CU (LDS-bound), fewer when there are fewer 64-query groups than waves
+            static int next_slot = 0;
+            static const int n_cu = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                return n;
+            }();
+            const int slot = (next_slot++) & 63;   // successive launches use different counter rows (streams may overlap)
+            const long groups = (long)((p.Lq + 63) / 64) * p.H * p.B;
+            const long wgs = (groups + 3) / 4 < 2l * n_cu ? (groups + 3) / 4 : 2l * n_cu;
+            hipLaunchKernelGGL(sparse_ctr_reset, dim3(1), dim3(64), 0, st, slot);
+            hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, p, slot);
+        }
         else if (p.mask_bits)
             hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
         else

@@ -850,8 +850,7 @@ inline bool ring_fits(const CcvGemm& p, int r) {
 // Which kernel runs a problem.  Fitted to the sweep of tools/gemm_tune.py on MI355X (profiles/r01_gemm_tune.txt):
 //  * linear layers (taps == 1): the 128x128 family (64-deep slabs, 2 workgroups per CU) wins or ties everywhere;
 //  * 3x3 / temporal convolutions: the 128x160 ring tile when its tile count fills the chip (with split-K to reach
-//    256-512 workgroups on the 16x16 .. 4x4 latent layers), the 128x320 tile for the longest K at 8x8 latents,
-//    the 128x128 family for long K at 32x32 latents where both tie and it needs no workspace.
+//    256-512 workgroups on the 16x16 .. 4x4 latent layers), the 128x320 tile for the longest K at 8x8 latents.
 inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     static const bool ring_on = [] { const char* e = getenv("CCV_GEMM_WIDE"); return !(e && e[0] == '0'); }();
     const int forced_ring = tune_env("CCV_GEMM_RING"), forced_split = tune_env("CCV_GEMM_SPLIT");
@@ -876,7 +875,7 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     if (p.taps == 1 || !ring_fits(p, 2)) return family();
     const long tiles2 = (long)((p.M + 127) / 128) * (p.N / 160);   // 128x160 tiles
     if (p.taps == 3) return tiles2 >= 512 ? ring(2, 1) : family();
-    if (tiles2 >= 512) return nslab <= 100 ? ring(2, 1) : family();
+    if (tiles2 >= 512) return ring(2, 1);
     if (ring_fits(p, 0) && nslab >= 480 && tiles2 <= 128 && tiles2 >= 64) return ring(0, (int)(512 / tiles2));
     int sp = (int)(256 / tiles2);
     if (sp < 1) sp = 1;

@@ -256,6 +256,26 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
     }
 }
 
+// Longest-first schedule of the sparse attention kernel: one workgroup per mask batch counts the needed key
+// blocks of every 64-query group (popcount of its wave_bits row) and rank-sorts the groups (O(n^2), n <= 8192,
+// once per clip).
+__global__ __launch_bounds__(256) void group_order_kernel(const uint32_t* wave_bits, int ngroups, int words, int32_t* order) {
+    __shared__ int cnt[8192];
+    const uint32_t* wb = wave_bits + (long)blockIdx.x * ngroups * words;
+    for (int i = threadIdx.x; i < ngroups; i += 256) {
+        int c = 0;
+        for (int w = 0; w < words; ++w) c += __popc(wb[(long)i * words + w]);
+        cnt[i] = c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ngroups; i += 256) {
+        const int ci = cnt[i];
+        int rank = 0;
+        for (int j = 0; j < ngroups; ++j) rank += (cnt[j] > ci || (cnt[j] == ci && j < i)) ? 1 : 0;
+        order[(long)blockIdx.x * ngroups + rank] = i;
+    }
+}
+
 }  // namespace
 
 extern "C" int ccv_pack_nchw_to_rows(const float* x, int32_t c1, const float* x2, int32_t c2, float* out, int32_t ldo,
@@ -363,5 +383,13 @@ extern "C" int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* f
     hipLaunchKernelGGL(epipolar_bits_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), F, bits, flags, wave_bits, T, H, W,
                        (float)downsample, words, ktiles, n, patch_order ? W : 0);
     CCV_LAUNCH_CHECK("ccv_epipolar_mask_bits");
+    return CCV_OK;
+}
+
+extern "C" int ccv_attn_group_order(const uint32_t* wave_bits, int32_t B, int32_t ngroups, int32_t wave_words, int32_t* order, void* stream) {
+    CCV_REQUIRE(wave_bits && order && B > 0 && ngroups > 0 && wave_words > 0, CCV_EINVAL, "ccv_attn_group_order: bad args");
+    CCV_REQUIRE(ngroups <= 8192, CCV_ESHAPE, "ccv_attn_group_order: at most 8192 query groups (Lq <= 524288)");
+    hipLaunchKernelGGL(group_order_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), wave_bits, ngroups, wave_words, order);
+    CCV_LAUNCH_CHECK("ccv_attn_group_order");
     return CCV_OK;
 }

@@ -42,6 +42,7 @@ class CcvAttn(C.Structure):
         ("mask_bits", vp), ("mask_bs", i64), ("mask_words", i32), ("mask_nb", i32),
         ("tile_flags", vp), ("flags_bs", i64), ("flags_ktiles", i32),
         ("wave_bits", vp), ("wave_bs", i64), ("wave_words", i32),
+        ("group_order", vp), ("order_bs", i64),
         ("kreg", vp), ("vreg", vp), ("nreg", i32),
         ("perm_hw", i32), ("perm_w", i32),
         ("variant", i32),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "ccv_ddim_cfg_step": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i64, vp, vp]),
     "ccv_pack_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ccv_epipolar_mask_bits": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ccv_attn_group_order": (i32, [vp, i32, i32, i32, vp, vp]),
 }
 
 _lib = None

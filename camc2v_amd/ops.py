@@ -116,7 +116,8 @@ LAST_GEMM_PLAN = None
 # ---------------------------------------------------------------------------------------
 def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_str=None, scale=None,
               k2=None, v2=None, k2_str=None, v2_str=None, Lk2=0, gate2=1.0,
-              mask_bits=None, mask_nb=1, tile_flags=None, wave_bits=None, kreg=None, vreg=None, variant=None, perm=None):
+              mask_bits=None, mask_nb=1, tile_flags=None, wave_bits=None, group_order=None, kreg=None, vreg=None, variant=None,
+              perm=None):
     """Fused attention, head dim 64.  *_str = (batch_outer, batch_inner, token) strides in elements;
     q/k/v are bf16 tensors whose data_ptr() is the element (batch 0, token 0, head 0, d 0).
     Returns bf16 [B*Lq, H*64] unless `out`/`o_str` are given."""
@@ -155,6 +156,11 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
             p.wave_bits = _ptr(wave_bits)
             p.wave_words = wave_bits.shape[-1]
             p.wave_bs = wave_bits.shape[-2] * wave_bits.shape[-1]
+            if group_order is not None:
+                if group_order.dtype != torch.int32 or not group_order.is_contiguous() or group_order.shape[-1] != wave_bits.shape[-2]:
+                    raise CcvError("attention: group_order must be contiguous int32 [mask_nb, ceil(Lq/64)]")
+                p.group_order = _ptr(group_order)
+                p.order_bs = group_order.shape[-1]
     if kreg is not None:
         p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
     if perm is not None:   # (frame tokens, frame width): rows and mask are in 4x8-patch order
@@ -290,13 +296,23 @@ def ddim_cfg_step(x, e_c, e_uc, noise, coef, scale, guidance_rescale, want_x0=Tr
 
 
 class MaskPack(tuple):
-    """(bits, flags) with the per-64-query-group key-block bitmap riding along as ``.wave_bits``; unpacks as a pair
-    so existing ``bits, flags = pack_mask(...)`` call sites keep working."""
+    """(bits, flags) with the per-64-query-group key-block bitmap and the longest-first group schedule riding along as
+    ``.wave_bits`` / ``.group_order``; unpacks as a pair so ``bits, flags = pack_mask(...)`` call sites keep working."""
 
-    def __new__(cls, bits, flags, wave_bits):
+    def __new__(cls, bits, flags, wave_bits, group_order=None):
         self = super().__new__(cls, (bits, flags))
         self.wave_bits = wave_bits
+        self.group_order = group_order
         return self
+
+
+def attn_group_order(wave_bits):
+    """wave_bits int32 [B, groups, words] -> int32 [B, groups]: groups by decreasing popcount (sparse-kernel schedule)."""
+    _dev(wave_bits)
+    B, groups, words = wave_bits.shape
+    order = torch.empty((B, groups), dtype=torch.int32, device=wave_bits.device)
+    check(lib().ccv_attn_group_order(_ptr(wave_bits), B, groups, words, _ptr(order), _stream()), "ccv_attn_group_order")
+    return order
 
 
 def patch_order_ok(H, W):
@@ -317,7 +333,7 @@ def pack_mask(mask, perm=None):
     wbits = torch.zeros((B, (Lq + 63) // 64, ((Lk + 31) // 32 + 31) // 32), dtype=torch.int32, device=mask.device)
     hw, w = perm if perm is not None else (0, 0)
     check(lib().ccv_pack_mask(_ptr(mask), _ptr(bits), _ptr(flags), _ptr(wbits), B, Lq, Lk, hw, w, _stream()), "ccv_pack_mask")
-    return MaskPack(bits, flags, wbits)
+    return MaskPack(bits, flags, wbits, attn_group_order(wbits))
 
 
 def epipolar_mask_bits(F, T, H, W, downsample, patch_order=False):
@@ -331,4 +347,4 @@ def epipolar_mask_bits(F, T, H, W, downsample, patch_order=False):
     wbits = torch.zeros((B, (L + 63) // 64, ((L + 31) // 32 + 31) // 32), dtype=torch.int32, device=F.device)
     check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), _ptr(wbits), B, T, H, W, downsample, int(patch_order),
                                        _stream()), "ccv_epipolar_mask_bits")
-    return MaskPack(bits, flags, wbits)
+    return MaskPack(bits, flags, wbits, attn_group_order(wbits))

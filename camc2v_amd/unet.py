@@ -293,12 +293,12 @@ class Epipolar(nn.Module, _Prepared):
         s = (L * ld, 0, ld)
         kw = {}
         if packed_mask is not None and not self.is_3d_full_attn:
-            bits, flags, nb, perm, wbits = packed_mask
+            bits, flags, nb, perm, wbits, order = packed_mask
             if bits.shape[1] != L:
                 raise CcvError(f"epipolar mask has {bits.shape[1]} query rows, feature map has {L} tokens")
             if perm is not None and perm != (g.h * g.w, g.w):
                 raise CcvError(f"epipolar mask was packed for frames {perm}, feature map is {g.h}x{g.w}")
-            kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm, wave_bits=wbits)
+            kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm, wave_bits=wbits, group_order=order)
         o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
                           kreg=pk.get("kreg"), vreg=pk.get("vreg"), scale=self.epipolar_attn.scale, **kw)
         ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
@@ -844,7 +844,8 @@ class UNetModel(nn.Module, _Prepared):
         masks = {}
         packed = camera_condition.get("sample_locs_packed")
         if packed is not None:
-            masks = {k: (v[0], v[1], v[0].shape[0], v[2] if len(v) > 2 else None, v[3] if len(v) > 3 else getattr(v, "wave_bits", None))
+            masks = {k: (v[0], v[1], v[0].shape[0], v[2] if len(v) > 2 else None, v[3] if len(v) > 3 else getattr(v, "wave_bits", None),
+                         v[4] if len(v) > 4 else getattr(v, "group_order", None))
                      for k, v in packed.items()}
         elif camera_condition.get("sample_locs_dict") is not None:
             origin_h = getattr(self, "epipolar_origin_h", 8 * H)
@@ -854,7 +855,7 @@ class UNetModel(nn.Module, _Prepared):
                 ww = (W * hh) // H if H else 0
                 perm = (hh * ww, ww) if (hh > 0 and ww > 0 and ops.patch_order_ok(hh, ww) and t * hh * ww == m.shape[1]) else None
                 mp = self._inputs.get(("mask", perm), m, lambda m=m, perm=perm: ops.pack_mask(m, perm))
-                masks[k] = (mp[0], mp[1], m.shape[0], perm, mp.wave_bits)
+                masks[k] = (mp[0], mp[1], m.shape[0], perm, mp.wave_bits, mp.group_order)
         return dict(rows=rows, masks=masks, add_type=camera_condition.get("add_type"))
 
     # ---- forward ----------------------------------------------------------------------------------------

@@ -139,12 +139,17 @@ typedef struct CcvAttn {
     const uint8_t* tile_flags; int64_t flags_bs; int32_t flags_ktiles;
     const uint32_t* wave_bits; int64_t wave_bs; int32_t wave_words; /* NULL or [mask_nb, ceil(Lq/64), wave_words] uint32: bit j of
                               * word w set => the 64-query group needs key block 32*(32w+j) .. +31 (any visible key) */
+    const int32_t* group_order; int64_t order_bs; /* NULL or [mask_nb, ceil(Lq/64)] int32 from ccv_attn_group_order: the 64-query
+                              * groups by decreasing number of needed key blocks; the persistent sparse kernel hands them
+                              * out in this order (longest first) so that the last waves to finish hold the cheapest groups */
     const uint16_t* kreg; const uint16_t* vreg; int32_t nreg;
     int32_t perm_hw, perm_w; /* token order of q/k/v/o rows and of the mask: 0 = as stored; otherwise the kernel walks each
                               * frame (perm_hw tokens, perm_w wide) in 4x8-pixel patches (index -> row map in ccv_patch_row);
                               * the mask must have been built with the same values */
     int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; two-context calls use kernel 1);
-                         1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging */
+                         1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging;
+                         3: as 0 but always the per-wave sparse kernel when wave_bits is given (0 picks it from 1024
+                            64-query groups upwards and the tiled masked kernel below that) */
 } CcvAttn;
 int ccv_attn_fwd(const CcvAttn* p, void* stream);
 
@@ -226,6 +231,10 @@ int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, uint32_t*
                   int32_t B, int32_t Lq, int32_t Lk, int32_t perm_hw, int32_t perm_w, void* stream);
 int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
                            int32_t B, int32_t T, int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream);
+/* Schedule of the sparse attention kernel (once per clip, after the mask was packed on the same stream):
+ * order[b][r] = index of the 64-query group with the r-th largest popcount of its wave_bits row (ties: lower index first).
+ * wave_bits [B, ngroups, wave_words], order [B, ngroups] int32; ngroups <= 8192. */
+int ccv_attn_group_order(const uint32_t* wave_bits, int32_t B, int32_t ngroups, int32_t wave_words, int32_t* order, void* stream);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,7 @@ def test_gemm_planner_host_logic(built):
     assert _plan(built, 32768, 2560, 320, geglu=1) == (-1, 1)
     assert _plan(built, 2048, 1280, 5120) == (-1, 2)                     # FF down-projection at 8x8 latents
     assert _plan(built, 32768, 320, 320, taps=9, gather=1) == (2, 1)     # conv3x3 at 32x32 latents: 128x160 ring tile
-    assert _plan(built, 32768, 320, 960, taps=9, gather=1) == (-1, 1)    # long K at 32x32: 128x128 family
+    assert _plan(built, 32768, 320, 960, taps=9, gather=1) == (2, 1)
     assert _plan(built, 8192, 640, 640, taps=9, gather=1) == (2, 2)
     assert _plan(built, 2048, 1280, 2560, taps=9, gather=1) == (0, 4)    # longest K at 8x8: 128x320 tile, split 4
     assert _plan(built, 512, 1280, 1280, taps=9, gather=1) == (2, 8)     # 4x4 latents: 32 tiles x 8 splits

@@ -350,7 +350,7 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
     # per-wave sparse kernel (block bitmap from the packer): same math, different schedule
     out3 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=(L * ld, 0, ld),
                          k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1, tile_flags=flags,
-                         wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, variant=variant)
+                         wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, variant=3 if variant == 0 else variant)
     assert_close(out3.reshape(B, L, H, 64), ref_attn(x[:, :, 0], k, v, m), 1.5e-2, f"sparse kernel L={L}")
     wb = mp.wave_bits.cpu().numpy().view(np.uint32)
     need = mask[0].reshape(-1, L).cpu()
@@ -360,6 +360,14 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
     ref_need = ref_need.reshape(nq, 64, nk, 32).any(3).any(1)
     got_need = np.unpackbits(wb.view(np.uint8), axis=-1, bitorder="little")[0, :, :nk].astype(bool)
     assert np.array_equal(got_need, ref_need.numpy())
+    # longest-first schedule: groups by decreasing number of needed key blocks, ties by index; same result with it
+    cnt = ref_need.sum(1).numpy()
+    want = np.array(sorted(range(nq), key=lambda i: (-cnt[i], i)), dtype=np.int32)
+    assert np.array_equal(mp.group_order.cpu().numpy()[0], want)
+    out4 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=(L * ld, 0, ld),
+                         k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1, tile_flags=flags,
+                         wave_bits=mp.wave_bits, group_order=mp.group_order, kreg=kreg, vreg=vreg, variant=3 if variant == 0 else variant)
+    assert torch.equal(out3, out4)   # each group is still computed by one wave in the same block order
 
 
 def test_attention_patch_order(ops):
@@ -382,7 +390,7 @@ def test_attention_patch_order(ops):
         outs.append(ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st,
                                   mask_bits=bits, mask_nb=1, tile_flags=flags, kreg=kreg, vreg=vreg, perm=perm))
         o_sparse = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st,
-                                 mask_bits=bits, mask_nb=1, wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, perm=perm)
+                                 mask_bits=bits, mask_nb=1, wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, perm=perm, variant=3)
         assert_close(o_sparse, outs[-1], 1e-2, f"sparse vs tiled, perm={perm}")
     x = qkv.float().reshape(B, L, 3, H, 64)
     k = torch.cat([kreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)

@@ -131,11 +131,14 @@ def bench_epi():
         s = (L * ld, 0, ld)
         us = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
                                           mask_bits=bits, mask_nb=1, tile_flags=flags, wave_bits=mp.wave_bits, kreg=kreg, vreg=vreg, perm=perm), iters=10)
+        us_l = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
+                                            mask_bits=bits, mask_nb=1, tile_flags=flags, wave_bits=mp.wave_bits, group_order=mp.group_order,
+                                            kreg=kreg, vreg=vreg, perm=perm), iters=10)
         us_t = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
                                             mask_bits=bits, mask_nb=1, tile_flags=flags, kreg=kreg, vreg=vreg, perm=perm), iters=10)
         us_d = timeit(lambda: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s),
                       iters=5)
-        print(f"  L={L:6d} H={H:2d} {'patch ' if patch else 'raster'}: sparse {us:8.1f} us, tiled {us_t:8.1f} us (dense-equivalent {4 * 2 * H * L * L * 64 / us / 1e6:7.1f} TF/s), "
+        print(f"  L={L:6d} H={H:2d} {'patch ' if patch else 'raster'}: sparse {us:8.1f} us, longest-first {us_l:8.1f} us, tiled {us_t:8.1f} us (dense-equivalent {4 * 2 * H * L * L * 64 / us_l / 1e6:7.1f} TF/s), "
               f"unmasked {us_d:8.1f} us ({4 * 2 * H * L * L * 64 / us_d / 1e6:7.1f} TF/s); "
               f"element density {dens:.3f}, 128x64 tile density {flags.float().mean().item():.3f}")
 
