@@ -96,47 +96,58 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
                                                  float inv_count, float eps) {
     __shared__ float s_sum[GN_GROUPS * 2];
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    if (threadIdx.x < 256) {
-        const int gk = threadIdx.x >> 2, j = threadIdx.x & 3;   // gk = 2*group + moment
-        const float* pp = partial + (long)inst * nchunk * GN_GROUPS * 2 + gk;
-        float v[GN_MAX_CHUNKS / 4];
-#pragma unroll
-        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) {
-            const int c = j + 4 * i;
-            v[i] = (c < nchunk) ? pp[(long)c * GN_GROUPS * 2] : 0.f;
-        }
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) a += v[i];
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        if (j == 0) s_sum[gk] = a;
-    }
-    __syncthreads();
     const int cols = C >> 2;
     const int col = threadIdx.x % cols, roff = threadIdx.x / cols, R = blockDim.x / cols;
     const int rows_per_chunk = (rows_per_instance + nchunk - 1) / nchunk;
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(rows_per_instance, r0 + rows_per_chunk);
+    const long base = (long)inst * rows_per_instance * cols + col;
+    constexpr int U = GN_UNROLL / 2;
+    // the first batch of rows and the affine parameters are requested before the statistics prologue, whose
+    // partial-sum loads would otherwise add a full memory round trip in front of them
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int rr = r0 + roff + u * R;
+        v[u] = (rr < r1) ? load4<X_F32>(x, base + (long)rr * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 gm = reinterpret_cast<const float4*>(gamma)[col];
+    const float4 bt = reinterpret_cast<const float4*>(beta)[col];
+    if (threadIdx.x < 256) {
+        const int gk = threadIdx.x >> 2, j = threadIdx.x & 3;   // gk = 2*group + moment
+        const float* pp = partial + (long)inst * nchunk * GN_GROUPS * 2 + gk;
+        float pv[GN_MAX_CHUNKS / 4];
+#pragma unroll
+        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) {
+            const int c = j + 4 * i;
+            pv[i] = (c < nchunk) ? pp[(long)c * GN_GROUPS * 2] : 0.f;
+        }
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) a += pv[i];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (j == 0) s_sum[gk] = a;
+    }
+    __syncthreads();
     const int cpg = C / GN_GROUPS;
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
     float sc[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int c = 4 * col + k, g = c / cpg;
+        const int g = (4 * col + k) / cpg;
         const float mean = s_sum[2 * g] * inv_count;
         const float var = fmaxf(s_sum[2 * g + 1] * inv_count - mean * mean, 0.f);
-        sc[k] = rsqrtf(var + eps) * gamma[c];
-        sh[k] = beta[c] - mean * sc[k];
+        sc[k] = rsqrtf(var + eps) * gmv[k];
+        sh[k] = btv[k] - mean * sc[k];
     }
-    const long base = (long)inst * rows_per_instance * cols + col;
     uint2* yo = reinterpret_cast<uint2*>(y);
-    constexpr int U = GN_UNROLL / 2;
     for (int r = r0 + roff; r < r1; r += U * R) {
-        float4 v[U];
+        float4 nv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = r + u * R;
-            v[u] = (rr < r1) ? load4<X_F32>(x, base + (long)rr * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < U; ++u) {      // next batch in flight while this one is normalised and stored
+            const int rr = r + (U + u) * R;
+            nv[u] = (rr < r1) ? load4<X_F32>(x, base + (long)rr * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -145,60 +156,172 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
             if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
             if (rr < r1) yo[base + (long)rr * cols] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = nv[u];
     }
 }
 
-// 16 lanes per row (4 rows per wave, 16 rows per 256-thread block); a lane owns float4 columns lane16 + 16*i,
-// so every load instruction reads 256 contiguous bytes of each of its 4 rows and every store writes 128.
-// Two-pass statistics on registers (mean, then centred sum of squares), reduced over the 16 lanes with shuffles.
-// LN_MAX4 = float4 columns per lane the instance is compiled for (C <= 64 * LN_MAX4): 5 covers C = 320 with 20
-// live registers instead of 128, which keeps 8 waves per SIMD resident for this bandwidth-bound pass.
-template <int LN_MAX4>
-__global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, const float* gamma, const float* beta,
-                                                 int rows, int C, float eps, const uint16_t* addend, int addend_rows, uint16_t* y2) {
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int l16 = threadIdx.x & 15;
-    const int cols = C >> 2;                 // float4 columns per row
-    const int per = (cols + 15) >> 4;        // per lane
-    const bool live = row < rows;
-    const float4* xr = reinterpret_cast<const float4*>(x) + (long)(live ? row : 0) * cols;
-    float4 v[LN_MAX4];
-    float s = 0.f;
+// Single-launch GroupNorm for instances whose per-group slice is small (the 16x16 .. 4x4 latent layers): grid
+// (32 / gpb, instances); a workgroup owns `gpb` adjacent groups of one instance (gpb * C/32 channels, >= 128
+// contiguous bytes per row), reads its slice once for the statistics and once more (an L1/L2 hit) to normalise.
+// No partials, no second launch: at these sizes two launches cost more than the bytes they move.  Fixed-order
+// reductions as above (bitwise reproducible).
+template <bool X_F32>
+__global__ __launch_bounds__(256) void gn_small(const void* x, uint16_t* y, const float* gamma, const float* beta,
+                                                int rows, int C, int gpb, int silu, float inv_count, float eps) {
+    __shared__ __attribute__((aligned(16))) float part[256 * 4];
+    __shared__ float colsum[64 * 4];
+    __shared__ float s_stat[GN_GROUPS * 2];
+    const int inst = blockIdx.y;
+    const int cpg = C / GN_GROUPS;
+    const int w4 = (cpg * gpb) >> 2;                 // float4 columns of this workgroup's channel span
+    const int c4 = threadIdx.x % w4, rr = threadIdx.x / w4, RS = 256 / w4;
+    const bool active = rr < RS;
+    const int cols = C >> 2;
+    const int col = blockIdx.x * w4 + c4;            // float4 column in the full row
+    const long base = (long)inst * rows * cols + col;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (active) {
+        for (int r = rr; r < rows; r += GN_UNROLL * RS) {
+            float4 v[GN_UNROLL];
 #pragma unroll
-    for (int i = 0; i < LN_MAX4; ++i) {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c = l16 + 16 * i;
-        if (i < per && c < cols) {
-            v[i] = xr[c];
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            for (int u = 0; u < GN_UNROLL; ++u) {
+                const int q = r + u * RS;
+                v[u] = (q < rows) ? load4<X_F32>(x, base + (long)q * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < GN_UNROLL; ++u) {
+                a0 += v[u].x + v[u].y; a1 += v[u].x * v[u].x + v[u].y * v[u].y;
+                a2 += v[u].z + v[u].w; a3 += v[u].z * v[u].z + v[u].w * v[u].w;
+            }
+        }
+        *reinterpret_cast<float4*>(part + (rr * w4 + c4) * 4) = make_float4(a0, a1, a2, a3);
+    }
+    const float4 gm = active ? reinterpret_cast<const float4*>(gamma)[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bt = active ? reinterpret_cast<const float4*>(beta)[col] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (threadIdx.x < w4 * 4) {                      // column sums over the RS row slots: part[ro][c4][comp], 8 reads in flight
+        float a = 0.f;
+        for (int ro = 0; ro < RS; ro += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (ro + u < RS) ? part[(ro + u) * w4 * 4 + threadIdx.x] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += t[u];
+        }
+        colsum[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * gpb) {
+        const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+        const int ppg = cpg >> 1;                    // channel pairs per group
+        float a = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < ppg; ++i) {
+            const int pr = g * ppg + i;              // pair inside the span -> float4 column pr/2, half pr&1
+            a += colsum[(pr >> 1) * 4 + (pr & 1) * 2 + k];
+        }
+        s_stat[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (!active) return;
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g = (4 * c4 + k) / cpg;            // group inside the span
+        const float mean = s_stat[2 * g] * inv_count;
+        const float var = fmaxf(s_stat[2 * g + 1] * inv_count - mean * mean, 0.f);
+        sc[k] = rsqrtf(var + eps) * gmv[k];
+        sh[k] = btv[k] - mean * sc[k];
+    }
+    uint2* yo = reinterpret_cast<uint2*>(y);
+    for (int r = rr; r < rows; r += GN_UNROLL * RS) {
+        float4 v[GN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int q = r + u * RS;
+            v[u] = (q < rows) ? load4<X_F32>(x, base + (long)q * cols) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int q = r + u * RS;
+            float o0 = v[u].x * sc[0] + sh[0], o1 = v[u].y * sc[1] + sh[1], o2 = v[u].z * sc[2] + sh[2], o3 = v[u].w * sc[3] + sh[3];
+            if (silu) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+            if (q < rows) yo[base + (long)q * cols] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
         }
     }
+}
+
+// groups per workgroup of gn_small (0: use the two-launch path): the span must be a whole number of float4 columns,
+// at least 128 bytes per row and at most 64 columns.  Measured on MI355X (tools/bench_kernels.py norm): the single
+// launch wins while one pass of a workgroup stays under ~24 KiB and there are >= 128 workgroups (frame-wise norms
+// at 8x8 and 4x4 latents: 6-10 us instead of 12-15 us); larger slices are faster through the chunked two-launch path.
+inline int gn_small_gpb(int instances, int rows_per_instance, int C, bool x_f32) {
+    const int cpg = C / GN_GROUPS;
+    for (int gpb = 1; gpb <= GN_GROUPS; gpb *= 2) {
+        const int span = cpg * gpb;
+        if (span % 4 != 0 || span * (x_f32 ? 4 : 2) < 128) continue;
+        if (span / 4 > 64) return 0;
+        const bool fits = (long)rows_per_instance * span * (x_f32 ? 4 : 2) <= (24l << 10);
+        return (fits && (long)instances * (GN_GROUPS / gpb) >= 128) ? gpb : 0;
+    }
+    return 0;
+}
+
+// LPR lanes per row (64/LPR rows per wave); a lane owns float4 columns l + LPR*i, so every load instruction of a
+// wave reads 16*LPR contiguous bytes of each of its rows and every store writes half of that.  Two-pass statistics
+// on registers (mean, then centred sum of squares), reduced over the LPR lanes with shuffles.  LN_MAX4 = float4
+// columns per lane the instance is compiled for (C <= 4 * LPR * LN_MAX4).  The layers here have C = 320 / 640 /
+// 1280 at 32768 / 8192 / 2048 rows: LPR = C/20 keeps 5 float4 (20 registers) per lane at every width, 8 waves per
+// SIMD resident, and the narrow-and-long as well as the wide-and-short activations spread over all CUs.
+template <int LPR, int LN_MAX4>
+__global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, const float* gamma, const float* beta,
+                                                 int rows, int C, float eps, const uint16_t* addend, int addend_rows, uint16_t* y2) {
+    constexpr int RPB = 256 / LPR;           // rows per block
+    const int row = blockIdx.x * RPB + (threadIdx.x / LPR);
+    const int l = threadIdx.x % LPR;
+    const int cols = C >> 2;                 // float4 columns per row
+    const bool live = row < rows;
+    const float4* xr = reinterpret_cast<const float4*>(x) + (long)(live ? row : 0) * cols;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 v[LN_MAX4], gm[LN_MAX4], bt[LN_MAX4];
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+    for (int i = 0; i < LN_MAX4; ++i) {    // every load of the kernel is issued here, before the first reduction
+        const int c = l + LPR * i;
+        const bool in = c < cols;
+        v[i] = in ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[i] = in ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[i] = in ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX4; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX4; ++i) {
-        const int c = l16 + 16 * i;
-        if (i < per && c < cols) {
+        const int c = l + LPR * i;
+        if (c < cols) {
             const float a = v[i].x - mean, b = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
             q += (a * a + b * b) + (d * d + e * e);
         }
     }
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
     const float rstd = rsqrtf(q / (float)C + eps);
     if (!live) return;
     uint2* yo = reinterpret_cast<uint2*>(y) + (long)row * cols;
     uint2* y2o = y2 ? reinterpret_cast<uint2*>(y2) + (long)row * cols : nullptr;
     const uint2* ad = addend ? reinterpret_cast<const uint2*>(addend) + (long)(row % addend_rows) * cols : nullptr;
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
     for (int i = 0; i < LN_MAX4; ++i) {
-        const int c = l16 + 16 * i;
-        if (i < per && c < cols) {
-            const float4 g = g4[c], bb = b4[c];
+        const int c = l + LPR * i;
+        if (c < cols) {
+            const float4 g = gm[i], bb = bt[i];
             const float o0 = (v[i].x - mean) * rstd * g.x + bb.x, o1 = (v[i].y - mean) * rstd * g.y + bb.y;
             const float o2 = (v[i].z - mean) * rstd * g.z + bb.z, o3 = (v[i].w - mean) * rstd * g.w + bb.w;
             yo[c] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
@@ -209,6 +332,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, co
             }
         }
     }
+}
+
+template <int LPR, int LN_MAX4>
+void launch_ln(hipStream_t st, const float* x, uint16_t* y, const float* gamma, const float* beta, int rows, int C, float eps,
+               const uint16_t* addend, int ar, uint16_t* y2) {
+    constexpr int RPB = 256 / LPR;
+    hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
 }
 
 }  // namespace
@@ -226,6 +356,18 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     CCV_REQUIRE(instances <= 65535, CCV_ESHAPE, "ccv_groupnorm: too many instances");
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm: C=%d must be a multiple of 64 and <= 4096", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const float inv_n = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
+    static const bool small_on = [] { const char* e = getenv("CCV_GN_SMALL"); return !(e && e[0] == '0'); }();
+    const int gpb = small_on ? gn_small_gpb(instances, rows_per_instance, C, x_f32 != 0) : 0;
+    if (gpb > 0) {
+        dim3 grid_s(GN_GROUPS / gpb, instances);
+        if (x_f32)
+            hipLaunchKernelGGL(gn_small<true>, grid_s, dim3(256), 0, st, x, y, gamma, beta, rows_per_instance, C, gpb, silu, inv_n, eps);
+        else
+            hipLaunchKernelGGL(gn_small<false>, grid_s, dim3(256), 0, st, x, y, gamma, beta, rows_per_instance, C, gpb, silu, inv_n, eps);
+        CCV_LAUNCH_CHECK("ccv_groupnorm(small)");
+        return CCV_OK;
+    }
     const int nchunk = gn_chunks(instances, rows_per_instance, C);
     const int nthreads = gn_threads(C);
     float* partial = static_cast<float*>(ws);
@@ -251,17 +393,16 @@ extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, co
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 2048, CCV_ESHAPE, "ccv_layernorm: C=%d must be a multiple of 64 and <= 2048", C);
     CCV_REQUIRE((addend == nullptr) == (y2 == nullptr), CCV_EINVAL, "ccv_layernorm: addend and y2 go together");
     CCV_REQUIRE(!addend || addend_rows > 0, CCV_EINVAL, "ccv_layernorm: addend_rows must be positive");
-    const dim3 grid((rows + 15) / 16);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ar = addend_rows > 0 ? addend_rows : 1;
     if (C <= 320)
-        hipLaunchKernelGGL(ln_kernel<5>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<16, 5>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else if (C <= 640)
-        hipLaunchKernelGGL(ln_kernel<10>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<32, 5>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else if (C <= 1280)
-        hipLaunchKernelGGL(ln_kernel<20>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<64, 5>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else
-        hipLaunchKernelGGL(ln_kernel<32>, grid, dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<64, 8>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     CCV_LAUNCH_CHECK("ccv_layernorm");
     return CCV_OK;
 }

@@ -434,7 +434,10 @@ def test_attention_softmax_rescale_spike(ops):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("C,inst,rpi,f32,silu", [(320, 6, 1024, True, True), (2560, 4, 16, True, True),
                                                  (64, 2, 4096, False, False), (1280, 2, 1024, False, True),
-                                                 (960, 3, 100, True, False)])
+                                                 (960, 3, 100, True, False),
+                                                 # single-launch path (small per-group slices, >= 128 workgroups)
+                                                 (320, 32, 16, True, True), (320, 32, 20, False, True),
+                                                 (1280, 32, 64, False, True), (640, 16, 37, True, False)])
 def test_groupnorm(ops, C, inst, rpi, f32, silu):
     x = rnd(inst * rpi, C, seed=40, dtype=torch.float32 if f32 else torch.bfloat16) * 2.0 + 0.5
     gamma = 1.0 + rnd(C, seed=41, dtype=torch.float32) * 0.1
@@ -447,7 +450,7 @@ def test_groupnorm(ops, C, inst, rpi, f32, silu):
     assert_close(y.reshape(inst, rpi, C), ref.permute(0, 2, 1), 1e-2, "groupnorm")
 
 
-@pytest.mark.parametrize("C", [64, 320, 512, 1280])
+@pytest.mark.parametrize("C", [64, 320, 512, 640, 1280, 2048])
 def test_layernorm(ops, C):
     rows = 1000
     x = rnd(rows, C, seed=43, dtype=torch.float32) * 3 + 1

@@ -16,13 +16,32 @@ torch.set_grad_enabled(False)
 
 
 def timeit(fn, iters=20, warm=3):
+    """Average device time of fn() in microseconds.  The calls are captured into a hipGraph and replayed, so that the
+    ~13 us of Python/ctypes launch cost per call does not hide kernels shorter than that (CCV_BENCH_EAGER=1: eager)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    if os.environ.get("CCV_BENCH_EAGER") == "1":
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3  # us
