@@ -59,13 +59,15 @@ __global__ void unpack_nchw_kernel(const float* in, int ldi, float* out, int c, 
 }
 
 // out[row] = [a[row, 0:ca] | b[row, 0:cb]] in float4 units
-__global__ void concat_rows_kernel(const float4* a, int ca4, const float4* b, int cb4, float4* out, int64_t rows) {
+__global__ void concat_rows_kernel(const float4* a, int ca4, const float4* b, int cb4, float4* out, uint2* out16, int64_t rows) {
     const int w = ca4 + cb4;
     const int64_t n = rows * w;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % w);
         const int64_t r = i / w;
-        out[i] = (c < ca4) ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+        const float4 v = (c < ca4) ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+        out[i] = v;
+        if (out16) out16[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
 }
 
@@ -298,13 +300,14 @@ extern "C" int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out,
     return CCV_OK;
 }
 
-extern "C" int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, int64_t rows, void* stream) {
+extern "C" int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, uint16_t* out_bf16, int64_t rows,
+                               void* stream) {
     CCV_REQUIRE(a && b && out && rows > 0, CCV_EINVAL, "ccv_concat_rows: bad args");
     CCV_REQUIRE(ca % 4 == 0 && cb % 4 == 0 && ca > 0 && cb > 0, CCV_ESHAPE, "ccv_concat_rows: channel counts must be multiples of 4");
     const int64_t n = rows * ((ca + cb) / 4);
     hipLaunchKernelGGL(concat_rows_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const float4*>(a), ca / 4, reinterpret_cast<const float4*>(b), cb / 4,
-                       reinterpret_cast<float4*>(out), rows);
+                       reinterpret_cast<float4*>(out), reinterpret_cast<uint2*>(out_bf16), rows);
     CCV_LAUNCH_CHECK("ccv_concat_rows");
     return CCV_OK;
 }

@@ -94,12 +94,17 @@ class LatentDiffusionCore(nn.Module):
         if self.model.conditioning_key != "hybrid":
             return self.apply_model(x, t, c, **kwargs), self.apply_model(x, t, uc, **kwargs)
         b = x.shape[0]
-        xc = torch.cat([torch.cat([x] + list(c["c_concat"]), 1), torch.cat([x] + list(uc["c_concat"]), 1)], 0)
         # a single context tensor is handed over as is: the UNet caches its K/V projections by tensor identity
         one = lambda parts: parts[0] if len(parts) == 1 else torch.cat(list(parts), 1)
         ctx = [one(c["c_crossattn"]), one(uc["c_crossattn"])]
         extra = {k: v for k, v in c.items() if k not in ("c_concat", "c_crossattn")}
         kw = dict(kwargs)
+        cc, ucc = list(c["c_concat"]), list(uc["c_concat"])
+        if len(cc) == len(ucc) and all(p is q for p, q in zip(cc, ucc)):
+            # both halves start from the very same tensors: the context-free head of the UNet runs once
+            out = self.model.diffusion_model(torch.cat([x] + cc, 1), t, context=ctx, cfg_shared_input=True, **extra, **kw)
+            return out[:b], out[b:]
+        xc = torch.cat([torch.cat([x] + cc, 1), torch.cat([x] + ucc, 1)], 0)
         if kw.get("fs") is not None:
             kw["fs"] = torch.cat([kw["fs"], kw["fs"]], 0)
         out = self.model.diffusion_model(xc, torch.cat([t, t], 0), context=ctx, **extra, **kw)

@@ -231,15 +231,17 @@ def unpack_rows_to_nchw(rows, c, b, t, h, w):
     return out
 
 
-def concat_rows(a, b):
+def concat_rows(a, b, with_bf16=False):
+    """[rows, ca] ++ [rows, cb] fp32; with_bf16 also returns the bf16 rounding of the result (out, out16)."""
     _dev(a, b)
     rows, ca = _rows(a)
     rows_b, cb = _rows(b)
     if rows != rows_b or a.dtype != F32 or b.dtype != F32:
         raise CcvError("concat_rows: fp32 inputs with equal row counts expected")
     out = torch.empty((rows, ca + cb), dtype=F32, device=a.device)
-    check(lib().ccv_concat_rows(_ptr(a), ca, _ptr(b), cb, _ptr(out), rows, _stream()), "ccv_concat_rows")
-    return out
+    out16 = torch.empty((rows, ca + cb), dtype=BF16, device=a.device) if with_bf16 else None
+    check(lib().ccv_concat_rows(_ptr(a), ca, _ptr(b), cb, _ptr(out), _ptr(out16), rows, _stream()), "ccv_concat_rows")
+    return (out, out16) if with_bf16 else out
 
 
 def cast_bf16(x):

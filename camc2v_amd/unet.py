@@ -579,8 +579,9 @@ class ResBlock(TimestepBlock, _Prepared):
             pk["skip_taps"] = 9 if sc.kernel_size[0] == 3 else 1
         return pk
 
-    def forward_rows(self, x, emb_all, g):
-        """x fp32 [(b t h w), Cin]; emb_all fp32 [b, sum Cout] (all ResBlock emb projections in one GEMM)."""
+    def forward_rows(self, x, emb_all, g, x_bf16=None):
+        """x fp32 [(b t h w), Cin]; emb_all fp32 [b, sum Cout] (all ResBlock emb projections in one GEMM);
+        x_bf16: optional bf16 rounding of x (what the skip convolution's operand load would produce anyway)."""
         pk = self._pk()
         cin, cout = self.channels, self.out_channels
         conv = (g.h, g.w, g.h, g.w, 1, 0)
@@ -592,10 +593,11 @@ class ResBlock(TimestepBlock, _Prepared):
         h = ops.groupnorm(h, pk["g2"], pk["b2"], instances=g.b * g.t, eps=1e-5, silu=True)
         skip = x
         if "ws" in pk:
+            xs = x_bf16 if x_bf16 is not None else x
             if pk["skip_taps"] == 9:
-                skip = ops.gemm(x, pk["ws"], k=cin, taps=9, bias=pk["bs"], out_f32=True, gather=ops.GATHER_CONV3X3, conv=conv)
+                skip = ops.gemm(xs, pk["ws"], k=cin, taps=9, bias=pk["bs"], out_f32=True, gather=ops.GATHER_CONV3X3, conv=conv)
             else:
-                skip = ops.gemm(x, pk["ws"], bias=pk["bs"], out_f32=True)
+                skip = ops.gemm(xs, pk["ws"], bias=pk["bs"], out_f32=True)
         out = ops.gemm(h, pk["w2"], k=cout, taps=9, bias=pk["cb2"], residual=skip, out_f32=True,
                        gather=ops.GATHER_CONV3X3, conv=conv)
         if self.use_temporal_conv:
@@ -859,18 +861,27 @@ class UNetModel(nn.Module, _Prepared):
         return dict(rows=rows, masks=masks, add_type=camera_condition.get("add_type"))
 
     # ---- forward ----------------------------------------------------------------------------------------
-    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, camera_condition=None, **kwargs):
+    def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, camera_condition=None,
+                cfg_shared_input=False, **kwargs):
         """x [b, in_channels, t, h, w]; timesteps [b]; context [b, L, context_dim] (or a list of such tensors
         covering consecutive batch slices); fs [b]; camera_condition as built by
         model/camcontexti2v.py:565-570.  Unknown kwargs are ignored like the reference does.  Returns fp32
-        [b, out_channels, t, h, w]."""
+        [b, out_channels, t, h, w].
+
+        cfg_shared_input: x / timesteps / fs hold ONE copy of the b0 samples while ``context`` (a list of two
+        tensors) and the camera condition describe 2*b0 samples -- the conditional and unconditional halves of a
+        classifier-free-guidance step.  Both halves see identical activations until the first cross-attention
+        (input conv, init_attn, the first ResBlock: none of them reads the context or the camera), so that prefix
+        runs once and is duplicated; the output then has 2*b0 samples."""
         if features_adapter is not None:
             raise NotImplementedError("features_adapter is not used on the generation path")
         if not x.is_cuda:
             raise CcvError("UNetModel.forward: the product path runs on the GPU only (see oracle/ for the CPU restatement)")
         pk = self._pk()
-        b, _, t, H, W = x.shape
-        g = Geom(b, t, H, W)
+        b0, _, t, H, W = x.shape
+        shared = bool(cfg_shared_input)
+        b = 2 * b0 if shared else b0
+        g = Geom(b0, t, H, W)          # geometry of the (possibly shared) prefix
         mc = self.model_channels
 
         # -- timestep / frame-stride embedding -> one fused projection for all ResBlocks ------------------
@@ -886,6 +897,7 @@ class UNetModel(nn.Module, _Prepared):
                 fs = torch.full((b,), self.default_fs, dtype=torch.long, device=x.device)
             emb_f = mlp("fps_embedding", fs)
         emb_all = ops.gemm(ops.add_silu_bf16(emb, emb_f), pk["w_emb"], bias=pk["b_emb"], out_f32=True)
+        emb_state = [emb_all]          # run() reads the current one; replaced after the shared prefix
 
         nclips, ctx_iter = self._context_groups(context, t)
         if nclips != b:
@@ -902,10 +914,11 @@ class UNetModel(nn.Module, _Prepared):
             mask = cam["masks"].get(origin_h // hh) if cam["masks"] else None
             return dict(rows=rows, mask=mask, add_type=cam["add_type"])
 
-        def run(block, h, g, level):
+        def run(block, h, g, level, h16=None):
             for layer in block:
                 if isinstance(layer, ResBlock):
-                    h = layer.forward_rows(h, emb_all, g)
+                    h = layer.forward_rows(h, emb_state[0], g, h16)
+                    h16 = None
                 elif isinstance(layer, SpatialTransformer):
                     h = layer.forward_rows(h, g, [next(ctx_iter) for _ in layer.transformer_blocks])
                 elif isinstance(layer, TemporalTransformer):
@@ -922,17 +935,36 @@ class UNetModel(nn.Module, _Prepared):
                      gather=ops.GATHER_CONV3X3, conv=(H, W, H, W, 1, 0))
         if self.addition_attention:
             h = self.init_attn[0].forward_rows(h, g, None)  # never camera conditioned (modified_forwards.py:80-81)
+        def widen(rows_b0):   # [b0 rows] -> [cond rows | uncond rows]
+            return torch.cat([rows_b0, rows_b0], 0)
+
         hs = [(h, g)]
         for i, block in enumerate(self.input_blocks):
             if i == 0:
                 continue
-            h, g = run(block, h, g, int(math.log2(self.input_ds[i])))
+            layers = list(block)
+            if shared and g.b == b0:
+                # the leading context-free layers of this block still run on the single copy
+                n_free = 0
+                while n_free < len(layers) and isinstance(layers[n_free], (ResBlock, Downsample)):
+                    n_free += 1
+                if n_free < len(layers):   # a transformer follows: duplicate here
+                    h, g = run(layers[:n_free], h, g, int(math.log2(self.input_ds[i])))
+                    h, g = widen(h), Geom(b, g.t, g.h, g.w)
+                    hs = [(widen(hh), Geom(b, gg.t, gg.h, gg.w)) for hh, gg in hs]
+                    emb_state[0] = widen(emb_all)
+                    layers = layers[n_free:]
+            h, g = run(layers, h, g, int(math.log2(self.input_ds[i])))
             hs.append((h, g))
+        if shared and g.b == b0:           # a UNet without any transformer in its encoder
+            h, g = widen(h), Geom(b, g.t, g.h, g.w)
+            hs = [(widen(hh), Geom(b, gg.t, gg.h, gg.w)) for hh, gg in hs]
+            emb_state[0] = widen(emb_all)
         h, g = run(self.middle_block, h, g, -1)
         for i, block in enumerate(self.output_blocks):
             skip, _ = hs.pop()
-            h = ops.concat_rows(h, skip)
-            h, g = run(block, h, g, int(math.log2(self.output_ds[i])))
+            h, h16 = ops.concat_rows(h, skip, with_bf16=True)   # the bf16 copy feeds the ResBlock's 1x1 skip convolution
+            h, g = run(block, h, g, int(math.log2(self.output_ds[i])), h16)
         y = ops.groupnorm(h, pk["gn_g"], pk["gn_b"], instances=g.b * g.t, eps=1e-5, silu=True)
         y = ops.gemm(y, pk["w_out"], k=mc, taps=9, bias=pk["b_out"], out_f32=True, gather=ops.GATHER_CONV3X3,
                      conv=(g.h, g.w, g.h, g.w, 1, 0))

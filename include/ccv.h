@@ -188,8 +188,9 @@ int ccv_pack_nchw_to_rows(const float* x, int32_t c1, const float* x2, int32_t c
 /* '(b t) c h w -> b c t h w' of the first c columns (openaimodel3d.py:623): in [rows, ldi] fp32. */
 int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out, int32_t c,
                             int32_t b, int32_t t, int32_t hw, void* stream);
-/* torch.cat([h, skip], dim=1) on token-major fp32 rows (openaimodel3d.py:617). */
-int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out,
+/* torch.cat([h, skip], dim=1) on token-major fp32 rows (openaimodel3d.py:617); out_bf16 (or NULL) receives the
+ * same rows rounded to bf16, the form the ResBlock's 1x1 skip convolution consumes as a GEMM operand. */
+int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, uint16_t* out_bf16,
                     int64_t rows, void* stream);
 /* fp32 -> bf16 (contexts, pose features) with an optional 'b c t h w -> (b t h w) c' transpose. */
 int ccv_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream);

@@ -478,6 +478,8 @@ def test_layout_roundtrip(ops):
     assert torch.equal(back, torch.cat([x, c], 1))
     a, bb = rnd(100, 64, seed=52, dtype=torch.float32), rnd(100, 128, seed=53, dtype=torch.float32)
     assert torch.equal(ops.concat_rows(a, bb), torch.cat([a, bb], 1))
+    cat32, cat16 = ops.concat_rows(a, bb, with_bf16=True)
+    assert torch.equal(cat32, torch.cat([a, bb], 1)) and torch.equal(cat16, torch.cat([a, bb], 1).to(torch.bfloat16))
     f = rnd(2, 320, 16, 4, 4, seed=54, dtype=torch.float32)
     assert torch.equal(ops.nchw_to_rows_bf16(f), f.permute(0, 2, 3, 4, 1).reshape(-1, 320).to(torch.bfloat16))
     assert torch.equal(ops.cast_bf16(a), a.to(torch.bfloat16))

@@ -125,6 +125,13 @@ def test_cfg_pair_equals_two_forwards(small):
     _check(y2[:2], y_c, "pair/cond half")     # this fixture amplifies any rounding difference ~1e4x (see header)
     _check(y2[2:], y_u, "pair/uncond half")
     _check(y2[:2], fx["y_cam_rep"], "pair/cond half vs reference fixture")
+    # shared-input form (what apply_model_pair uses when both halves start from the same tensors): the context-free
+    # head of the UNet runs once on b samples and is duplicated in front of the first transformer
+    y3 = unet(g["x"], g["t"], context=[g["ctx_rep"], g["ctx_pf"]], fs=g["fs"], camera_condition=cam, cfg_shared_input=True)
+    assert y3.shape == y2.shape
+    _check(y3[:2], y_c, "shared-input pair/cond half")
+    _check(y3[2:], y_u, "shared-input pair/uncond half")
+    _check(y3[:2], fx["y_cam_rep"], "shared-input pair/cond half vs reference fixture")
 
 
 def test_native_packed_masks_equal_bool_masks(small):
