@@ -519,7 +519,7 @@ struct WaitSlab<PER, 0> {
 };
 
 template <int MT, int NT, int ST, int GATHER>
-__global__ __launch_bounds__(256) void gemm_ring_kernel(const CcvGemm p) {
+__global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_ring_kernel(const CcvGemm p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 64;           // A pieces (16 rows of 64 B = one DMA wave-instruction) per wave and slab
     constexpr int BP = BN / 16;           // B pieces per slab in total
@@ -819,13 +819,14 @@ int launch_ring(const CcvGemm& p, hipStream_t st) {
 // ---- kernel selection -----------------------------------------------------------------------------------
 // ring configurations: block tile and ring depth
 struct RingCfg { int bm, bn, st; };
-constexpr int N_RING = 5;
+constexpr int N_RING = 6;
 const RingCfg kRing[N_RING] = {
     {128, 320, 4},   // 112 KiB LDS, 1 workgroup per CU
     {64, 320, 4},    //  96 KiB
     {128, 160, 4},   //  72 KiB, 2 per CU
     {64, 160, 4},    //  56 KiB, 2 per CU
     {64, 160, 8},    // 112 KiB
+    {128, 320, 2},   //  56 KiB, 2 per CU (register budget 256 per lane)
 };
 
 struct Plan {
@@ -848,9 +849,11 @@ inline bool ring_fits(const CcvGemm& p, int r) {
 }
 
 // Which kernel runs a problem.  Fitted to the sweep of tools/gemm_tune.py on MI355X (profiles/r01_gemm_tune.txt):
-//  * linear layers (taps == 1): the 128x128 family (64-deep slabs, 2 workgroups per CU) wins or ties everywhere;
-//  * 3x3 / temporal convolutions: the 128x160 ring tile when its tile count fills the chip (with split-K to reach
-//    256-512 workgroups on the 16x16 .. 4x4 latent layers), the 128x320 tile for the longest K at 8x8 latents.
+//  * linear layers (taps == 1): the 128x128 family (64-deep slabs, 2 workgroups per CU) wins or ties, except the
+//    GEGLU up-projections (N = 8C), which take the 2-stage 128x320 tile (2 workgroups per CU, up to 770 TFLOP/s);
+//  * 3x3 / temporal convolutions: long K (>= 256 slabs of 32) on the 2-stage 128x320 tile with split-K up to ~512
+//    workgroups (up to 910 TFLOP/s), shorter K on the 128x160 ring tile (with split-K to reach 256-512 workgroups
+//    on the 16x16 .. 4x4 latent layers).
 inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     static const bool ring_on = [] { const char* e = getenv("CCV_GEMM_WIDE"); return !(e && e[0] == '0'); }();
     const int forced_ring = tune_env("CCV_GEMM_RING"), forced_split = tune_env("CCV_GEMM_SPLIT");
@@ -872,11 +875,19 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     };
     if (forced_ring == -1 || !ring_on || p.a_f32) return family();
     if (forced_ring >= 0) return ring_fits(p, forced_ring) ? ring(forced_ring, forced_split > 0 ? forced_split : 1) : family();
-    if (p.taps == 1 || !ring_fits(p, 2)) return family();
+    const long tiles0 = (long)((p.M + 127) / 128) * (p.N / 320);   // 128x320 tiles (meaningful when N % 320 == 0)
+    const int no5 = tune_env("CCV_GEMM_NO5");                      // tuning aid: 1 = no GEGLU rule, 2 = no conv rule, 3 = neither
+    if (p.taps == 1) {
+        // GEGLU up-projections (N = 8C): the 128x320 tile at two workgroups per CU once it fills them
+        if (p.geglu && ring_fits(p, 5) && tiles0 >= 512 && !(no5 > 0 && (no5 & 1))) return ring(5, 1);
+        return family();
+    }
+    if (!ring_fits(p, 2)) return family();
     const long tiles2 = (long)((p.M + 127) / 128) * (p.N / 160);   // 128x160 tiles
     if (p.taps == 3) return tiles2 >= 512 ? ring(2, 1) : family();
+    // long-K 3x3 convolutions: 128x320 tiles, two workgroups per CU, split-K up to ~512 workgroups
+    if (ring_fits(p, 5) && nslab >= 256 && tiles0 >= 64 && !(no5 > 0 && (no5 & 2))) return ring(5, (int)(tiles0 >= 512 ? 1 : 512 / tiles0));
     if (tiles2 >= 512) return ring(2, 1);
-    if (ring_fits(p, 0) && nslab >= 480 && tiles2 <= 128 && tiles2 >= 64) return ring(0, (int)(512 / tiles2));
     int sp = (int)(256 / tiles2);
     if (sp < 1) sp = 1;
     if (tiles2 >= 256 && nslab / sp >= 180) sp *= 2;
@@ -900,7 +911,8 @@ int dispatch_ring(const CcvGemm& p, int ring, hipStream_t st) {
         case 1: return launch_ring<2, 10, 4, GATHER>(p, st);
         case 2: return launch_ring<4, 5, 4, GATHER>(p, st);
         case 3: return launch_ring<2, 5, 4, GATHER>(p, st);
-        default: return launch_ring<2, 5, 8, GATHER>(p, st);
+        case 4: return launch_ring<2, 5, 8, GATHER>(p, st);
+        default: return launch_ring<4, 10, 2, GATHER>(p, st);
     }
 }
 

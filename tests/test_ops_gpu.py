@@ -198,7 +198,7 @@ def test_gemm_wide_tile_paths(ops):
     assert_close(out.reshape(b, t, hw, 320).permute(0, 3, 1, 2), reft[..., 0], 2e-3, "wide tconv3")
 
 
-@pytest.mark.parametrize("ring,split", [(0, 1), (0, 2), (1, 1), (1, 3), (2, 1), (2, 4), (3, 1), (3, 2), (4, 1), (4, 2)])
+@pytest.mark.parametrize("ring,split", [(0, 1), (0, 2), (1, 1), (1, 3), (2, 1), (2, 4), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2)])
 def test_gemm_ring_configs(ops, ring, split, monkeypatch):
     """Every LDS-ring tile configuration (128x320, 64x320, 128x160, 64x160 with a 4- and 8-deep ring), unsplit and
     split-K, forced through the tuning variables: ragged-M linear with residual, GEGLU, conv3x3 with padding,
@@ -214,7 +214,7 @@ def test_gemm_ring_configs(ops, ring, split, monkeypatch):
     assert_close(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref + res, 2e-3, "ring linear + residual")
     assert ops.LAST_GEMM_PLAN == (ring, split)
     assert_close(ops.gemm(a, w, bias=bias, act=ops.ACT_SILU), F.silu(ref), 1e-2, "ring linear + SiLU, bf16 out")
-    if ring in (0, 1):   # GEGLU pairs 16-column groups inside a wave tile: 320-wide tiles only
+    if ring in (0, 1, 5):   # GEGLU pairs 16-column groups inside a wave tile: 320-wide tiles only
         wg, bg = rnd(640, K, seed=185, scale=0.02), rnd(640, seed=186, dtype=torch.float32)
         wp, bp = interleave_geglu(wg, bg)
         val, gate = (a.float() @ wg.float().t() + bg).chunk(2, dim=-1)
