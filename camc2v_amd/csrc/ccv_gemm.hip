@@ -519,7 +519,7 @@ struct WaitSlab<PER, 0> {
 };
 
 template <int MT, int NT, int ST, int GATHER>
-__global__ __launch_bounds__(256, (ST == 2 ? 2 : 1)) void gemm_ring_kernel(const CcvGemm p) {
+__global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void gemm_ring_kernel(const CcvGemm p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 64;           // A pieces (16 rows of 64 B = one DMA wave-instruction) per wave and slab
     constexpr int BP = BN / 16;           // B pieces per slab in total
@@ -819,7 +819,7 @@ int launch_ring(const CcvGemm& p, hipStream_t st) {
 // ---- kernel selection -----------------------------------------------------------------------------------
 // ring configurations: block tile and ring depth
 struct RingCfg { int bm, bn, st; };
-constexpr int N_RING = 6;
+constexpr int N_RING = 8;
 const RingCfg kRing[N_RING] = {
     {128, 320, 4},   // 112 KiB LDS, 1 workgroup per CU
     {64, 320, 4},    //  96 KiB
@@ -827,6 +827,8 @@ const RingCfg kRing[N_RING] = {
     {64, 160, 4},    //  56 KiB, 2 per CU
     {64, 160, 8},    // 112 KiB
     {128, 320, 2},   //  56 KiB, 2 per CU (register budget 256 per lane)
+    {128, 160, 2},   //  36 KiB, 3 per CU
+    {64, 320, 2},    //  48 KiB, 3 per CU
 };
 
 struct Plan {
@@ -912,7 +914,9 @@ int dispatch_ring(const CcvGemm& p, int ring, hipStream_t st) {
         case 2: return launch_ring<4, 5, 4, GATHER>(p, st);
         case 3: return launch_ring<2, 5, 4, GATHER>(p, st);
         case 4: return launch_ring<2, 5, 8, GATHER>(p, st);
-        default: return launch_ring<4, 10, 2, GATHER>(p, st);
+        case 5: return launch_ring<4, 10, 2, GATHER>(p, st);
+        case 6: return launch_ring<4, 5, 2, GATHER>(p, st);
+        default: return launch_ring<2, 10, 2, GATHER>(p, st);
     }
 }
 

@@ -16,7 +16,7 @@ from camc2v_amd import ops, pack  # noqa: E402
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 ops.TRACK_GEMM_PLAN = True
-RINGS = {-1: "128fam", 0: "128x320", 1: "64x320", 2: "128x160", 3: "64x160/4", 4: "64x160/8", 5: "128x320/2"}
+RINGS = {-1: "128fam", 0: "128x320", 1: "64x320", 2: "128x160", 3: "64x160/4", 4: "64x160/8", 5: "128x320/2", 6: "128x160/2", 7: "64x320/2"}
 
 
 def timeit(fn, iters=12, warm=2):
