@@ -251,3 +251,65 @@ def test_module_level_api(small):
     _check(blk.attn2(x.cuda(), context=ctx.cuda()),
            unet_oracle.cross_attention(sd, p + ".attn2", x, ctx, 1, True), "attn2 module")
     _check(blk.ff(x.cuda()), unet_oracle.feed_forward(sd, p + ".ff", x), "ff module")
+
+
+def _oracle_masks(T, px, cond_index=0):
+    """Epipolar masks of the synthetic benchmark trajectory from the geometry oracle (bool, per downsample key)."""
+    from oracle import geometry_oracle as go
+    K = torch.tensor([[px / 2, 0, px / 2], [0, px / 2, px / 2], [0, 0, 1.0]]).repeat(1, T, 1, 1)
+    w2c = go.synthetic_trajectory(1, T)
+    _, masks = go.camera_masks(K, w2c, torch.full((1,), cond_index, dtype=torch.long), px, px, resolutions=(8, 4, 2, 1))
+    return masks
+
+
+def _cfg_trajectory_vs_oracle(unet, sd, target, T, steps, scale, eta, tol):
+    """BASELINE.json configs[3]/[4]-style check: a short CFG DDIM trajectory of the camera-conditioned model, both
+    contexts per-frame (77 + 16 T tokens), through the reference-shaped wrapper `target`, against the fp32 oracle
+    UNet + oracle sampler run here on the CPU with the same weights, inputs and noise draws."""
+    from oracle import ddim_oracle, unet_oracle
+    from oracle.golden_inputs import SMALL_CFG, small_inputs
+    from utils.utils import instantiate_from_config
+    dev = torch.device("cuda:0")
+    inp = small_inputs(b=1, T=T, seed=77 + T)
+    masks = _oracle_masks(T, 64)
+    g = torch.Generator().manual_seed(T)
+    ctx_uc = torch.randn(1, 77 + 16 * T, 1024, generator=g)
+    noises = [torch.randn(1, 4, T, 8, 8, generator=g) for _ in range(steps)]
+    cam_cpu = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks,
+                   cond_frame_index=torch.zeros(1, dtype=torch.long), add_type="add_to_main_branch")
+
+    def eps(ctx):
+        return lambda x, t: unet_oracle.unet_forward(sd, SMALL_CFG, torch.cat([x, inp["c_concat"]], 1), t, ctx, inp["fs"],
+                                                     cam_cpu, origin_h=64)
+
+    with torch.no_grad():
+        ref, _ = ddim_oracle.ddim_sample(eps(inp["ctx_pf"]), eps(ctx_uc), inp["x_T"], steps, eta, scale, 0.7, noises)
+    core = instantiate_from_config({"target": target, "params": dict(
+        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG},
+        linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4, image_size=[8, 8],
+        temporal_length=T)})
+    core.model.diffusion_model = unet
+    core = core.to(dev)
+    to = lambda t: t.to(dev)
+    cam = dict(pluker_embedding_features=[to(f) for f in inp["feats"]], sample_locs_dict={d: to(m) for d, m in masks.items()},
+               cond_frame_index=torch.zeros(1, dtype=torch.long, device=dev), add_type="add_to_main_branch")
+    cc = to(inp["c_concat"])
+    cond = dict(c_concat=[cc], c_crossattn=[to(inp["ctx_pf"])], camera_condition=cam)
+    uncond = dict(c_concat=[cc], c_crossattn=[to(ctx_uc)])
+    samples, _ = core.sample_log(cond, 1, True, steps, eta=eta, x_T=inp["x_T"], unconditional_guidance_scale=scale,
+                                 unconditional_conditioning=uncond, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                 fs=to(inp["fs"]), enable_camera_condition=True, injected_noise=noises)
+    _check(samples, ref.numpy(), f"{target} T={T} CFG {scale}: {steps}-step trajectory vs oracle", *tol)
+
+
+def test_cami2v_baseline_config_trajectory(small):
+    """configs[3]: the CamI2V baseline target (epipolar path, ctx 77+16t on both CFG passes), same checkpoint layout."""
+    unet, _, sd, _, _, _, _ = small
+    _cfg_trajectory_vs_oracle(unet, sd, "baseline.cami2v.CamI2V", T=16, steps=2, scale=7.5, eta=1.0, tol=(1e-1, 2e-1))
+
+
+def test_32_frame_clip_cfg_3p5(small):
+    """configs[4] at UNet level: a 32-frame clip (temporal attention over 32 frames, epipolar attention over 32*h*w
+    tokens, context rule 77 + 16*32) at CFG 3.5 against the oracle."""
+    unet, _, sd, _, _, _, _ = small
+    _cfg_trajectory_vs_oracle(unet, sd, "model.camcontexti2v.CamContextI2V", T=32, steps=2, scale=3.5, eta=0.0, tol=(1e-1, 2e-1))
