@@ -258,6 +258,34 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
     }
 }
 
+// softmax over the last axis: x fp32 [rows, ldx] -> y bf16 [rows, ldy], one wave per row, three passes over a row that
+// stays in L1/L2 (rows here are 1024 logits of the first-stage decoder's single-head attention)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, uint16_t* y, int rows, int L, long ldx, long ldy) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    const int n4 = L >> 2;
+    float m = -3.0e38f;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = xr[i];
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = xr[i];
+        s += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    uint2* yr = reinterpret_cast<uint2*>(y + (long)row * ldy);
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = xr[i];
+        yr[i] = make_uint2(pack_bf16x2(__expf(v.x - m) * inv, __expf(v.y - m) * inv), pack_bf16x2(__expf(v.z - m) * inv, __expf(v.w - m) * inv));
+    }
+}
+
 // Longest-first schedule of the sparse attention kernel: one workgroup per mask batch counts the needed key
 // blocks of every 64-query group (popcount of its wave_bits row) and rank-sorts the groups (O(n^2), n <= 8192,
 // once per clip).
@@ -394,5 +422,14 @@ extern "C" int ccv_attn_group_order(const uint32_t* wave_bits, int32_t B, int32_
     CCV_REQUIRE(ngroups <= 8192, CCV_ESHAPE, "ccv_attn_group_order: at most 8192 query groups (Lq <= 524288)");
     hipLaunchKernelGGL(group_order_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), wave_bits, ngroups, wave_words, order);
     CCV_LAUNCH_CHECK("ccv_attn_group_order");
+    return CCV_OK;
+}
+
+extern "C" int ccv_softmax_rows(const float* x, uint16_t* y, int32_t rows, int32_t L, int64_t ldx, int64_t ldy, void* stream) {
+    CCV_REQUIRE(x && y && rows > 0 && L > 0, CCV_EINVAL, "ccv_softmax_rows: bad args");
+    CCV_REQUIRE(L % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= L && ldy >= L, CCV_ESHAPE,
+                "ccv_softmax_rows: L and the leading dimensions must be multiples of 4 (L=%d)", L);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, rows, L, (long)ldx, (long)ldy);
+    CCV_LAUNCH_CHECK("ccv_softmax_rows");
     return CCV_OK;
 }

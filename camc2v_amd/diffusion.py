@@ -43,8 +43,15 @@ class LatentDiffusionCore(nn.Module):
 
     def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
                  cosine_s=8e-3, parameterization="eps", conditioning_key=None, channels=3, image_size=256,
-                 temporal_length=None, use_dynamic_rescale=False, rescale_betas_zero_snr=False, **ignored):
+                 temporal_length=None, use_dynamic_rescale=False, rescale_betas_zero_snr=False,
+                 first_stage_config=None, scale_factor=1.0, perframe_ae=False, encoder_type="2d", **ignored):
         super().__init__()
+        # first-stage decoder: optional -- the DDIM path itself never touches it
+        self.scale_factor, self.perframe_ae, self.encoder_type = float(scale_factor), bool(perframe_ae), encoder_type
+        if first_stage_config is not None:
+            self.first_stage_model = instantiate_from_config(first_stage_config).eval()
+            for p_ in self.first_stage_model.parameters():
+                p_.requires_grad = False
         if parameterization != "eps" or use_dynamic_rescale or rescale_betas_zero_snr:
             raise NotImplementedError("only eps-parameterised, statically scaled schedules are shipped")
         self.parameterization = parameterization
@@ -109,6 +116,26 @@ class LatentDiffusionCore(nn.Module):
             kw["fs"] = torch.cat([kw["fs"], kw["fs"]], 0)
         out = self.model.diffusion_model(xc, torch.cat([t, t], 0), context=ctx, **extra, **kw)
         return out[:b], out[b:]
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, **kwargs):
+        """Latents [b, c, t, h, w] (or [n, c, h, w]) -> frames, reference ddpm3d.py:648-673: 1/scale_factor, every frame a
+        batch element of the 2-D decoder (perframe_ae decodes them one by one: same result, less memory)."""
+        fsm = getattr(self, "first_stage_model", None)
+        if fsm is None:
+            raise CcvError("decode_first_stage: the model was built without first_stage_config")
+        five = z.dim() == 5
+        if five:
+            b, c, t, hh, ww = z.shape
+            z = z.permute(0, 2, 1, 3, 4).reshape(b * t, c, hh, ww)
+        z = z.float() * (1.0 / self.scale_factor)
+        if self.perframe_ae:
+            out = torch.cat([fsm.decode(z[i:i + 1], **kwargs) for i in range(z.shape[0])], 0)
+        else:
+            out = fsm.decode(z, **kwargs)
+        if five:
+            out = out.reshape(b, t, out.shape[1], out.shape[2], out.shape[3]).permute(0, 2, 1, 3, 4)
+        return out
 
     @torch.no_grad()
     def sample_log(self, cond, batch_size, ddim, ddim_steps, **kwargs):

@@ -244,6 +244,17 @@ def concat_rows(a, b, with_bf16=False):
     return (out, out16) if with_bf16 else out
 
 
+def softmax_rows(x):
+    """fp32 [rows, L] (last dim contiguous) -> bf16 softmax over the last axis."""
+    _dev(x)
+    if x.dtype != F32 or x.dim() != 2 or x.stride(1) != 1:
+        raise CcvError("softmax_rows: fp32 [rows, L] with a contiguous last dim expected")
+    rows, L = x.shape
+    y = torch.empty((rows, L), dtype=BF16, device=x.device)
+    check(lib().ccv_softmax_rows(_ptr(x), _ptr(y), rows, L, x.stride(0), L, _stream()), "ccv_softmax_rows")
+    return y
+
+
 def cast_bf16(x):
     _dev(x)
     x = x.contiguous()

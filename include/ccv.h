@@ -193,6 +193,9 @@ int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out, int32_t c,
  * same rows rounded to bf16, the form the ResBlock's 1x1 skip convolution consumes as a GEMM operand. */
 int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, uint16_t* out_bf16,
                     int64_t rows, void* stream);
+/* Row softmax fp32 [rows, ldx] -> bf16 [rows, ldy] over L columns: the single-head, 512-wide attention of the first-stage
+ * decoder (lvdm/modules/networks/ae_modules.py:66-70) runs as GEMM (QK^T, alpha = C^-1/2) -> this -> GEMM (P V). */
+int ccv_softmax_rows(const float* x, uint16_t* y, int32_t rows, int32_t L, int64_t ldx, int64_t ldy, void* stream);
 /* fp32 -> bf16 (contexts, pose features) with an optional 'b c t h w -> (b t h w) c' transpose. */
 int ccv_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 int ccv_nchw_to_rows_bf16(const float* x, uint16_t* y, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);

@@ -97,3 +97,31 @@ def test_instantiate_from_config_contract():
         instantiate_from_config({"params": {}})
     m = instantiate_from_config({"target": "torch.nn.Linear", "params": {"in_features": 3, "out_features": 2}})
     assert isinstance(m, torch.nn.Linear)
+
+
+def test_first_stage_state_dict_matches_reference_manifest(golden_dir):
+    """AutoencoderKL through the reference's import path and yaml-style config: same 248 keys and shapes as the
+    reference's module (full-size and fixture-size configs), strict load, encoder is a parameter container."""
+    import json
+    import os
+
+    import pytest
+    import torch
+
+    from oracle import vae_oracle as vo
+    from oracle.unet_oracle import seeded_state_dict
+    from utils.utils import instantiate_from_config
+    for name, cfg in (("full", vo.FULL_DDCONFIG), ("small", vo.SMALL_DDCONFIG)):
+        man = json.load(open(os.path.join(golden_dir, f"vae_{name}_manifest.json")))
+        with torch.device("meta" if name == "full" else "cpu"):
+            m = instantiate_from_config({"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                         "params": dict(embed_dim=4, monitor="val/rec_loss", ddconfig=dict(cfg),
+                                                        lossconfig={"target": "torch.nn.Identity"})})
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
+        if name == "small":
+            m.load_state_dict(seeded_state_dict(man, 1), strict=True)
+            with pytest.raises(NotImplementedError):
+                m.encode(torch.zeros(1, 3, 64, 64))
+            from camc2v_amd.lib import CcvError
+            with pytest.raises(CcvError):          # no CPU fallback
+                m.decode(torch.zeros(1, 4, 8, 8))

@@ -194,3 +194,19 @@ def test_geometry_masks_bit_exact(golden_dir):
         assert nflip == 0, f"d={d}: {nflip} mask bits differ"
         m = geometry_oracle.epipolar_mask(F256, 256 // d, 256 // d, d)
         assert np.array_equal(m.sum(-1).to(torch.int32).numpy(), fx[f"mask256_d{d}_popcount_rows"]), d
+
+
+def test_vae_decode_oracle_vs_reference_fixture(golden_dir):
+    """First-stage decoder restatement (oracle/vae_oracle.py) against the reference's AutoencoderKL.decode run by
+    oracle/gen_golden_vae.py: full decode, the activation after the middle block, and the clip-level entry."""
+    from oracle import vae_oracle as vo
+    fx = dict(np.load(os.path.join(golden_dir, "vae_small.npz")))
+    man = json.load(open(os.path.join(golden_dir, "vae_small_manifest.json")))
+    sd = unet_oracle.seeded_state_dict(man, int(fx["seed"]), std=float(fx["std"]))
+    z = torch.from_numpy(fx["z"])
+    _close(vo.decode(sd, vo.SMALL_DDCONFIG, z), fx["y"])
+    zq = torch.nn.functional.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    h = torch.nn.functional.conv2d(zq, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    h = vo.resnet_block(sd, "decoder.mid.block_2", vo.attn_block(sd, "decoder.mid.attn_1", vo.resnet_block(sd, "decoder.mid.block_1", h)))
+    _close(h, fx["mid"])
+    _close(vo.decode_first_stage(sd, vo.SMALL_DDCONFIG, torch.from_numpy(fx["z5"])), fx["y5"])
