@@ -746,11 +746,22 @@ int launch(const CcvGemm& p, hipStream_t st) {
 }
 
 // Tile shape for a problem: the largest tile that still yields >= ~1 workgroup per CU (256 CUs).
+inline int tune_env(const char* name);
 inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
+    const int forced = tune_env("CCV_GEMM_FAMTILE");   // tuning aid: 44 / 24 / 42 / 22
+    if (forced == 44 || forced == 24 || forced == 42 || forced == 22) {
+        mt = forced / 10; nt = forced % 10;
+        if ((nt == 4 && p.N % 128 != 0) || (nt == 2 && p.N % 64 != 0)) { mt = 2; nt = 2; }
+        return;
+    }
     auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    if (p.N % 128 == 0 && tiles(128, 128) >= 256) { mt = 4; nt = 4; return; }
-    if (p.N % 128 == 0 && tiles(64, 128) >= 256) { mt = 2; nt = 4; return; }
-    if (p.N % 64 == 0 && tiles(128, 64) >= 320) { mt = 4; nt = 2; return; }
+    // measured on MI355X (tools/famtile_probe.py): the loop hides its DMA latency only with two or more workgroups per
+    // CU in flight, so a tile size is taken once it yields >= 1.5 workgroups per CU (256 CUs); e.g. 8192x640x640:
+    // 128x128 (320 tiles) 24.4 us, 64x128 (640 tiles) 20.3 us; 2048x1280x1280: 64x128 22.9 us, 64x64 19.3 us
+    const long want = tune_env("CCV_GEMM_WANT") > 0 ? tune_env("CCV_GEMM_WANT") : 384;
+    if (p.N % 128 == 0 && tiles(128, 128) >= want) { mt = 4; nt = 4; return; }
+    if (p.N % 128 == 0 && tiles(64, 128) >= want) { mt = 2; nt = 4; return; }
+    if (p.N % 64 == 0 && tiles(128, 64) >= (want == 256 ? 320 : want)) { mt = 4; nt = 2; return; }
     mt = 2; nt = 2;
 }
 
