@@ -897,14 +897,15 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     }
     if (!ring_fits(p, 2)) return family();
     const long tiles2 = (long)((p.M + 127) / 128) * (p.N / 160);   // 128x160 tiles
-    if (p.taps == 3) return tiles2 >= 512 ? ring(2, 1) : family();
+    const int r160 = (no5 > 0 && (no5 & 4)) ? 6 : 2;               // tuning aid: 2-stage instead of 4-stage 128x160 tile
+    if (p.taps == 3) return tiles2 >= 512 ? ring(r160, 1) : family();
     // long-K 3x3 convolutions: 128x320 tiles, two workgroups per CU, split-K up to ~512 workgroups
     if (ring_fits(p, 5) && nslab >= 256 && tiles0 >= 64 && !(no5 > 0 && (no5 & 2))) return ring(5, (int)(tiles0 >= 512 ? 1 : 512 / tiles0));
-    if (tiles2 >= 512) return ring(2, 1);
+    if (tiles2 >= 512) return ring(r160, 1);
     int sp = (int)(256 / tiles2);
     if (sp < 1) sp = 1;
     if (tiles2 >= 256 && nslab / sp >= 180) sp *= 2;
-    return ring(2, sp);
+    return ring(r160, sp);
 }
 
 inline bool dma_enabled() {  // CCV_GEMM_DMA=0 falls back to the register-staged loop (tuning aid)

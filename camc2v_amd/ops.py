@@ -244,6 +244,18 @@ def concat_rows(a, b, with_bf16=False):
     return (out, out16) if with_bf16 else out
 
 
+def layernorm_small(x, gamma, beta, *, eps=1e-5):
+    """x fp32 [rows, >= C] (first C = gamma.numel() columns used, C <= 64) -> fp32 [rows, C]."""
+    _dev(x, gamma, beta)
+    if x.dtype != F32 or x.dim() != 2 or x.stride(1) != 1:
+        raise CcvError("layernorm_small: fp32 [rows, C'] with a contiguous last dim expected")
+    Cc = gamma.numel()
+    y = torch.empty((x.shape[0], Cc), dtype=F32, device=x.device)
+    check(lib().ccv_layernorm_small(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), x.shape[0], Cc, x.stride(0), eps, _stream()),
+          "ccv_layernorm_small")
+    return y
+
+
 def softmax_rows(x):
     """fp32 [rows, L] (last dim contiguous) -> bf16 softmax over the last axis."""
     _dev(x)

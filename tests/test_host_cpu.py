@@ -125,3 +125,27 @@ def test_first_stage_state_dict_matches_reference_manifest(golden_dir):
             from camc2v_amd.lib import CcvError
             with pytest.raises(CcvError):          # no CPU fallback
                 m.decode(torch.zeros(1, 4, 8, 8))
+
+
+def test_adaptor_state_dict_matches_reference_manifest(golden_dir):
+    """MultiLatentEpipolarAdaptor through the reference's import path: same keys and shapes as the reference's module
+    (shipped and fixture configurations); options outside the shipped configuration refuse loudly."""
+    import json
+    import os
+
+    import pytest
+    import torch
+
+    from oracle import adaptor_oracle as ao
+    from utils.utils import instantiate_from_config
+    for name, cfg in (("full", ao.FULL_CFG), ("small", ao.SMALL_CFG)):
+        man = json.load(open(os.path.join(golden_dir, f"adaptor_{name}_manifest.json")))
+        with torch.device("meta" if name == "full" else "cpu"):
+            m = instantiate_from_config({"target": "model.modules.adaptors.MultiLatentEpipolarAdaptor", "params": dict(cfg)})
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
+    with pytest.raises(NotImplementedError):
+        instantiate_from_config({"target": "model.modules.adaptors.MultiLatentEpipolarAdaptor",
+                                 "params": dict(ao.SMALL_CFG, use_plucker_embedding=True)})
+    from camc2v_amd.lib import CcvError
+    with pytest.raises(CcvError):
+        m(torch.zeros(1, 32, 4))

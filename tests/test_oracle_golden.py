@@ -210,3 +210,16 @@ def test_vae_decode_oracle_vs_reference_fixture(golden_dir):
     h = vo.resnet_block(sd, "decoder.mid.block_2", vo.attn_block(sd, "decoder.mid.attn_1", vo.resnet_block(sd, "decoder.mid.block_1", h)))
     _close(h, fx["mid"])
     _close(vo.decode_first_stage(sd, vo.SMALL_DDCONFIG, torch.from_numpy(fx["z5"])), fx["y5"])
+
+
+def test_adaptor_oracle_vs_reference_fixture(golden_dir):
+    """MultiLatentEpipolarAdaptor restatement (oracle/adaptor_oracle.py) against the reference's module run by
+    oracle/gen_golden_adaptor.py (masked with a registers-only row, and unmasked)."""
+    from oracle import adaptor_oracle as ao
+    fx = dict(np.load(os.path.join(golden_dir, "adaptor_small.npz")))
+    man = json.load(open(os.path.join(golden_dir, "adaptor_small_manifest.json")))
+    sd = unet_oracle.seeded_state_dict(man, int(fx["seed"]), std=float(fx["std"]))
+    x = torch.from_numpy(fx["x"])
+    mask = _unbits(fx["mask"], x.shape[1])
+    _close(ao.adaptor_forward(sd, ao.SMALL_CFG, x, mask), fx["y"])
+    _close(ao.adaptor_forward(sd, ao.SMALL_CFG, x, None), fx["y_nomask"])
