@@ -90,6 +90,10 @@ def lib():
             raise CcvError(
                 f"{LIB_PATH} is missing: build it with `python -m camc2v_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback on the product path.")
+        # torch first: its wheel carries its own libamdhip64, and device pointers / streams handed to the kernels come
+        # from that runtime; loading libccv_hip.so before torch would bind it to /opt/rocm's copy (a second runtime
+        # instance in the process: launches then fail with "no ROCm-capable device is detected")
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
