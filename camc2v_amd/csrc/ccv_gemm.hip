@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
             const int img = m / pix, rem = m - img * pix;
             const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
             a_base[i] = (m < p.M) ? img * p.src_h * p.src_w : -1;
-            a_y[i] = oy * p.stride - 1;
-            a_x[i] = ox * p.stride - 1;
+            a_y[i] = oy * p.stride - (p.no_lead_pad ? 0 : 1);
+            a_x[i] = ox * p.stride - (p.no_lead_pad ? 0 : 1);
         } else {
             a_base[i] = (m < p.M) ? m : -1;
             a_y[i] = (m / p.hw) % p.frames;  // frame index within the clip
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
             const int img = m / pix, rem = m - img * pix;
             const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
             a_base[j] = (m < p.M) ? img * p.src_h * p.src_w : -1;
-            a_y[j] = oy * p.stride - 1;
-            a_x[j] = ox * p.stride - 1;
+            a_y[j] = oy * p.stride - (p.no_lead_pad ? 0 : 1);
+            a_x[j] = ox * p.stride - (p.no_lead_pad ? 0 : 1);
         } else {
             a_base[j] = (m < p.M) ? m : -1;
             a_y[j] = (m / p.hw) % p.frames;
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             const int img = m / pix, rem = m - img * pix;
             const int oy = rem / p.out_w, ox = rem - oy * p.out_w;
             a_base[j] = (m < p.M) ? img * p.src_h * p.src_w : -1;
-            a_y[j] = oy * p.stride - 1;
-            a_x[j] = ox * p.stride - 1;
+            a_y[j] = oy * p.stride - (p.no_lead_pad ? 0 : 1);
+            a_x[j] = ox * p.stride - (p.no_lead_pad ? 0 : 1);
         } else {
             a_base[j] = (m < p.M) ? m : -1;
             a_y[j] = (m / p.hw) % p.frames;

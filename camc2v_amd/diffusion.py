@@ -118,6 +118,29 @@ class LatentDiffusionCore(nn.Module):
         return out[:b], out[b:]
 
     @torch.no_grad()
+    def encode_first_stage(self, x, noise=None):
+        """Frames [b, 3, t, H, W] (or [n, 3, H, W]) -> latents, reference ddpm3d.py:621-646: every frame a batch element of
+        the 2-D encoder, scale_factor * posterior.sample() (``noise``: the N(0,1) draw to use, shaped like the latents)."""
+        fsm = getattr(self, "first_stage_model", None)
+        if fsm is None:
+            raise CcvError("encode_first_stage: the model was built without first_stage_config")
+        five = x.dim() == 5
+        if five:
+            b, c, t, hh, ww = x.shape
+            x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, hh, ww)
+            if noise is not None:
+                noise = noise.permute(0, 2, 1, 3, 4).reshape(b * t, *noise.shape[1:2], *noise.shape[3:])
+        if self.perframe_ae:
+            zs = [fsm.encode(x[i:i + 1]).sample(None if noise is None else noise[i:i + 1]) for i in range(x.shape[0])]
+            z = torch.cat(zs, 0)
+        else:
+            z = fsm.encode(x).sample(noise)
+        z = self.scale_factor * z
+        if five:
+            z = z.reshape(b, t, z.shape[1], z.shape[2], z.shape[3]).permute(0, 2, 1, 3, 4)
+        return z
+
+    @torch.no_grad()
     def decode_first_stage(self, z, **kwargs):
         """Latents [b, c, t, h, w] (or [n, c, h, w]) -> frames, reference ddpm3d.py:648-673: 1/scale_factor, every frame a
         batch element of the 2-D decoder (perframe_ae decodes them one by one: same result, less memory)."""

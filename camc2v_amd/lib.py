@@ -19,7 +19,7 @@ class CcvGemm(C.Structure):
         ("lda", i32), ("ldc", i32), ("ldr", i32), ("ldb2", i32),
         ("a_f32", i32), ("gather", i32),
         ("out_h", i32), ("out_w", i32), ("src_h", i32), ("src_w", i32),
-        ("stride", i32), ("upsample", i32), ("frames", i32), ("hw", i32),
+        ("stride", i32), ("upsample", i32), ("no_lead_pad", i32), ("frames", i32), ("hw", i32),
         ("rows_per_batch", i32), ("act", i32), ("geglu", i32), ("out_f32", i32),
         ("alpha", f32),
         ("ws", vp), ("ws_bytes", i64), ("split_k", i32),

@@ -51,7 +51,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     """out[m, n] = epilogue(sum_tap gather(a) @ w_tap^T).  See include/ccv.h (ccv_gemm).
 
     a: [rows, lda] bf16 or fp32 (2-D, last dim contiguous); w: [N, taps*K] bf16.
-    conv = (out_h, out_w, src_h, src_w, stride, upsample); tconv = (frames, hw).
+    conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw).
     """
     _dev(a, w, bias, bias2, residual, out)
     if a.dim() != 2 or a.stride(1) != 1:
@@ -88,7 +88,8 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         raise CcvError("gemm: out dtype mismatch")
     p.gather = gather
     if gather == GATHER_CONV3X3:
-        p.out_h, p.out_w, p.src_h, p.src_w, p.stride, p.upsample = conv
+        p.out_h, p.out_w, p.src_h, p.src_w, p.stride, p.upsample = conv[:6]
+        p.no_lead_pad = int(conv[6]) if len(conv) > 6 else 0
     elif gather == GATHER_TCONV3:
         p.frames, p.hw = tconv
     p.rows_per_batch = rows_per_batch

@@ -3,8 +3,8 @@ after the DDIM path, turning the sampler's latents into frames).
 
 Same class, attribute and ``state_dict`` names as the reference (lvdm/models/autoencoder.py:13-199,
 lvdm/modules/networks/ae_modules.py:150-212, 24-82, 117-132, 364-583), so a ``first_stage_model.*`` checkpoint slice
-loads strictly.  Only ``decode`` is built: the encoder is a parameter container (it runs once per clip on the
-conditioning image, before the path; ``encode`` raises).
+loads strictly.  ``decode`` follows the path (latents -> frames); ``encode`` runs once per clip on the conditioning and
+context frames in front of it (frames -> posterior parameters -> latents).
 
 Execution: activations stay token-major ``[(n h w), C]`` like in the UNet; GroupNorm(32)+swish is ``ccv_groupnorm``;
 every 3x3 conv (incl. the nearest-2x upsample convs) is the implicit-GEMM ``ccv_gemm`` with bias / residual fused; the
@@ -130,14 +130,28 @@ class Upsample(nn.Module, _Prepared):
         return y, g2
 
 
-class Downsample(nn.Module):
-    """Parameter container (encoder side, reference ae_modules.py:95-115)."""
+class Downsample(nn.Module, _Prepared):
+    """F.pad(x, (0,1,0,1)) + stride-2 conv3x3 (reference ae_modules.py:95-115): the conv gather pads only after the
+    last row / column (``no_lead_pad``)."""
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
+        if not with_conv:
+            raise NotImplementedError("resamp_with_conv=False is not used by the first-stage model")
         self.with_conv, self.in_channels = with_conv, in_channels
-        if with_conv:
-            self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, 2, 0)
+
+    def _pack(self):
+        return dict(w=pack.pack_conv3x3(self.conv.weight), b=_dev_f32(self.conv.bias))
+
+    def forward_rows(self, x, g):
+        pk = self._pk()
+        if g.h % 2 or g.w % 2:
+            raise CcvError("Downsample: odd feature-map sizes are not produced by the shipped configuration")
+        g2 = _Geo(g.n, g.h // 2, g.w // 2)
+        y = ops.gemm(ops.cast_bf16(x), pk["w"], k=self.in_channels, taps=9, m=g.n * g2.h * g2.w, bias=pk["b"], out_f32=True,
+                     gather=ops.GATHER_CONV3X3, conv=(g2.h, g2.w, g.h, g.w, 2, 0, 1))
+        return y, g2
 
 
 def _mid(block_in):
@@ -148,9 +162,8 @@ def _mid(block_in):
     return mid
 
 
-class Encoder(nn.Module):
-    """Parameter container with the reference layout (ae_modules.py:364-468); not on the generation path after the
-    conditioning image has been encoded, so no forward here."""
+class Encoder(nn.Module, _Prepared):
+    """conv_in -> levels of 2 ResnetBlocks + Downsample -> mid -> GN+swish+conv_out (reference ae_modules.py:364-468)."""
 
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
                  resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, **ignored):
@@ -158,6 +171,7 @@ class Encoder(nn.Module):
         if list(attn_resolutions):
             raise NotImplementedError("attn_resolutions is empty in the shipped first-stage config")
         self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
+        self.in_channels = in_channels
         self.conv_in = nn.Conv2d(in_channels, ch, 3, 1, 1)
         in_ch_mult = (1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
@@ -176,9 +190,40 @@ class Encoder(nn.Module):
         self.mid = _mid(block_in)
         self.norm_out = Normalize(block_in)
         self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, 1, 1)
+        self.mid_channels, self.out_channels = block_in, self.conv_out.out_channels
+
+    def _pack(self):
+        return dict(in_pad=(self.in_channels + 63) // 64 * 64,
+                    w_in=pack.pack_conv3x3(self.conv_in.weight), b_in=_dev_f32(self.conv_in.bias),
+                    g=_dev_f32(self.norm_out.weight), b=_dev_f32(self.norm_out.bias),
+                    w_out=pack.pack_conv3x3(self.conv_out.weight), b_out=pack.pad_bias(self.conv_out.bias))
+
+    def forward_rows(self, x_rows, g, out=None):
+        """x_rows fp32 [(n H W), in_pad] zero padded -> fp32 rows [(n H/8 W/8), 16k] (first out_channels columns valid);
+        ``out`` may be a (strided) view to write into."""
+        pk = self._pk()
+        h = ops.gemm(x_rows, pk["w_in"], k=pk["in_pad"], taps=9, bias=pk["b_in"], out_f32=True, gather=ops.GATHER_CONV3X3, conv=g.conv)
+        for i_level in range(self.num_resolutions):
+            for blk in self.down[i_level].block:
+                h = blk.forward_rows(h, g)
+            if i_level != self.num_resolutions - 1:
+                h, g = self.down[i_level].downsample.forward_rows(h, g)
+        h = self.mid.block_1.forward_rows(h, g)
+        h = self.mid.attn_1.forward_rows(h, g)
+        h = self.mid.block_2.forward_rows(h, g)
+        y = ops.groupnorm(h, pk["g"], pk["b"], instances=g.n, eps=1e-6, silu=True)
+        y = ops.gemm(y, pk["w_out"], k=self.mid_channels, taps=9, bias=pk["b_out"], out_f32=True, out=out,
+                     gather=ops.GATHER_CONV3X3, conv=g.conv)
+        return y, g
 
     def forward(self, x):
-        raise NotImplementedError("the first-stage encoder runs before the generation path and is not built")
+        """x [n, 3, H, W] -> [n, 2*z_channels, H/8, W/8] (fp32)."""
+        if not x.is_cuda:
+            raise CcvError("Encoder.forward: the product path runs on the GPU only (see oracle/vae_oracle.py)")
+        n, c, hh, ww = x.shape
+        rows = ops.pack_nchw_to_rows(x.float().reshape(n, c, 1, hh, ww), None, ldo=self._pk()["in_pad"])
+        y, g = self.forward_rows(rows, _Geo(n, hh, ww))
+        return ops.unpack_rows_to_nchw(y, self.out_channels, n, 1, g.h, g.w).reshape(n, self.out_channels, g.h, g.w)
 
 
 class Decoder(nn.Module, _Prepared):
@@ -247,6 +292,28 @@ class Decoder(nn.Module, _Prepared):
         return ops.unpack_rows_to_nchw(y, self.out_ch, n, 1, g.h, g.w).reshape(n, self.out_ch, g.h, g.w)
 
 
+class DiagonalGaussianDistribution:
+    """Posterior of the first-stage encoder (reference lvdm/distributions.py:24-40): parameters = (mean | logvar)."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, noise=None):
+        if noise is None:
+            noise = torch.randn_like(self.mean)
+        return self.mean + self.std * noise.to(self.mean.device)
+
+    def mode(self):
+        return self.mean
+
+
 class AutoencoderKL(nn.Module, _Prepared):
     """Reference lvdm/models/autoencoder.py:13-199, decode side."""
 
@@ -275,10 +342,26 @@ class AutoencoderKL(nn.Module, _Prepared):
 
     def _pack(self):
         return dict(w_pq=pack.pack_linear(self.post_quant_conv.weight), b_pq=pack.pad_bias(self.post_quant_conv.bias),
-                    pad=(self.embed_dim + 63) // 64 * 64)
+                    pad=(self.embed_dim + 63) // 64 * 64,
+                    w_q=pack.pack_linear(self.quant_conv.weight), b_q=pack.pad_bias(self.quant_conv.bias),
+                    q_pad=(self.quant_conv.in_channels + 63) // 64 * 64)
 
+    @torch.no_grad()
     def encode(self, x, **kwargs):
-        raise NotImplementedError("the first-stage encoder runs before the generation path and is not built")
+        """x [n, 3, H, W] -> DiagonalGaussianDistribution over [n, embed_dim, H/8, W/8] (reference autoencoder.py:97-101)."""
+        if not x.is_cuda:
+            raise CcvError("AutoencoderKL.encode: the product path runs on the GPU only (see oracle/vae_oracle.py)")
+        pk = self._pk()
+        enc = self.encoder
+        n, c, hh, ww = x.shape
+        rows = ops.pack_nchw_to_rows(x.float().reshape(n, c, 1, hh, ww), None, ldo=enc._pk()["in_pad"])
+        # conv_out writes its 2*z_channels columns into a zeroed 64-wide row buffer: the quant_conv (1x1) operand
+        n_out = enc._pk()["w_out"].shape[0]
+        hq = torch.zeros((n * (hh // 8) * (ww // 8), pk["q_pad"]), dtype=torch.float32, device=x.device)
+        _, g = enc.forward_rows(rows, _Geo(n, hh, ww), out=hq[:, :n_out])
+        mom = ops.gemm(hq, pk["w_q"], bias=pk["b_q"], out_f32=True)
+        moments = ops.unpack_rows_to_nchw(mom, 2 * self.embed_dim, n, 1, g.h, g.w).reshape(n, 2 * self.embed_dim, g.h, g.w)
+        return DiagonalGaussianDistribution(moments)
 
     @torch.no_grad()
     def decode(self, z, **kwargs):
@@ -300,4 +383,4 @@ class AutoencoderKL(nn.Module, _Prepared):
         raise NotImplementedError("encode + decode round trips are a training-side operation")
 
 
-__all__ = ["AutoencoderKL", "Decoder", "Encoder", "ResnetBlock", "AttnBlock", "Upsample", "Downsample", "CcvError"]
+__all__ = ["AutoencoderKL", "DiagonalGaussianDistribution", "Decoder", "Encoder", "ResnetBlock", "AttnBlock", "Upsample", "Downsample", "CcvError"]

@@ -81,6 +81,9 @@ typedef struct CcvGemm {
     int32_t src_h, src_w;   /* gather 1: stored source image size (before upsample) */
     int32_t stride;         /* gather 1: 1 or 2 */
     int32_t upsample;       /* gather 1: 0/1 */
+    int32_t no_lead_pad;    /* gather 1: 0 = one pixel of zero padding on every side (padding=1); 1 = zero padding only
+                             * after the last row / column: F.pad(x, (0,1,0,1)) + stride-2 conv of the first-stage
+                             * encoder's Downsample (lvdm/modules/networks/ae_modules.py:106-110) */
     int32_t frames, hw;     /* gather 2: frames per clip, pixels per frame */
     int32_t rows_per_batch; /* bias2 row = m / rows_per_batch */
     int32_t act;            /* 0 none, 1 SiLU, 2 GELU(erf) */

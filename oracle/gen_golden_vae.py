@@ -70,12 +70,22 @@ def main():
     frames = (z5.permute(0, 2, 1, 3, 4).reshape(3, 4, 8, 8)) * (1.0 / vo.SCALE_FACTOR)
     y5 = small.decode(frames).reshape(1, 3, 3, 64, 64).permute(0, 2, 1, 3, 4)
 
+    # encoder side: 2 images -> posterior parameters, and a sample with a supplied noise draw
+    img = torch.randn(2, 3, 64, 64, generator=g)
+    post = small.encode(img)
+    enc_noise = torch.randn(2, 4, 8, 8, generator=g)
+    enc_sample = post.sample(enc_noise)
+    err_e = (vo.encode_moments(sd, vo.SMALL_DDCONFIG, img) - post.parameters).abs().max().item()
+    err_s = (vo.posterior_sample(post.parameters, enc_noise) - enc_sample).abs().max().item()
+    assert err_e < 2e-4 * post.parameters.abs().max().item() and err_s < 1e-5, (err_e, err_s)
+
     # the restatement must agree before anything is written
     err = (vo.decode(sd, vo.SMALL_DDCONFIG, z) - y).abs().max().item()
     err5 = (vo.decode_first_stage(sd, vo.SMALL_DDCONFIG, z5) - y5).abs().max().item()
     assert err < 2e-4 * y.abs().max().item() and err5 < 2e-4 * y5.abs().max().item(), (err, err5)
     np.savez_compressed(os.path.join(args.out, "vae_small.npz"), z=z.numpy(), y=y.numpy(), mid=mid.numpy(),
-                        z5=z5.numpy(), y5=y5.numpy(), seed=np.int64(gg.SEED + 11), std=np.float32(0.03))
+                        z5=z5.numpy(), y5=y5.numpy(), img=img.numpy(), moments=post.parameters.numpy(), enc_noise=enc_noise.numpy(),
+                        enc_sample=enc_sample.numpy(), seed=np.int64(gg.SEED + 11), std=np.float32(0.03))
     print(f"vae_small: y absmax {y.abs().max().item():.3f}, oracle max abs err {err:.2e} / {err5:.2e}; "
           f"{len(man)} tensors ({sum(int(np.prod(s)) for s in man.values()) / 1e6:.1f} M params)")
 

@@ -101,7 +101,7 @@ def test_instantiate_from_config_contract():
 
 def test_first_stage_state_dict_matches_reference_manifest(golden_dir):
     """AutoencoderKL through the reference's import path and yaml-style config: same 248 keys and shapes as the
-    reference's module (full-size and fixture-size configs), strict load, encoder is a parameter container."""
+    reference's module (full-size and fixture-size configs), strict load, no CPU fallback."""
     import json
     import os
 
@@ -120,10 +120,10 @@ def test_first_stage_state_dict_matches_reference_manifest(golden_dir):
         assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
         if name == "small":
             m.load_state_dict(seeded_state_dict(man, 1), strict=True)
-            with pytest.raises(NotImplementedError):
-                m.encode(torch.zeros(1, 3, 64, 64))
             from camc2v_amd.lib import CcvError
             with pytest.raises(CcvError):          # no CPU fallback
+                m.encode(torch.zeros(1, 3, 64, 64))
+            with pytest.raises(CcvError):
                 m.decode(torch.zeros(1, 4, 8, 8))
 
 

@@ -210,6 +210,10 @@ def test_vae_decode_oracle_vs_reference_fixture(golden_dir):
     h = vo.resnet_block(sd, "decoder.mid.block_2", vo.attn_block(sd, "decoder.mid.attn_1", vo.resnet_block(sd, "decoder.mid.block_1", h)))
     _close(h, fx["mid"])
     _close(vo.decode_first_stage(sd, vo.SMALL_DDCONFIG, torch.from_numpy(fx["z5"])), fx["y5"])
+    # encoder side: posterior parameters and a sample with the fixture's noise draw
+    mom = vo.encode_moments(sd, vo.SMALL_DDCONFIG, torch.from_numpy(fx["img"]))
+    _close(mom, fx["moments"])
+    _close(vo.posterior_sample(mom, torch.from_numpy(fx["enc_noise"])), fx["enc_sample"])
 
 
 def test_adaptor_oracle_vs_reference_fixture(golden_dir):

@@ -45,11 +45,10 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.set_grad_enabled(False)
-    man = {k: list(v.shape) for k, v in AutoencoderKL(ddconfig=dict(vo.FULL_DDCONFIG), embed_dim=4).state_dict().items()
-           if not k.startswith(("encoder.", "quant_conv."))}
+    man = {k: list(v.shape) for k, v in AutoencoderKL(ddconfig=dict(vo.FULL_DDCONFIG), embed_dim=4).state_dict().items()}
     sd = seeded_state_dict(man, 7, std=0.03)
     vae = AutoencoderKL(ddconfig=dict(vo.FULL_DDCONFIG), embed_dim=4)
-    vae.load_state_dict(sd, strict=False)
+    vae.load_state_dict(sd, strict=True)
     vae = vae.to(dev).eval()
     g = torch.Generator().manual_seed(9)
     z = torch.randn(args.frames, 4, 32, 32, generator=g)
@@ -63,10 +62,23 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fl = decoder_flops(vo.FULL_DDCONFIG, 32) * args.frames
+    # encode side: the conditioning frame + 2 context frames of a clip (3 images 256x256 -> posterior parameters)
+    img = torch.randn(3, 3, 256, 256, generator=g).to(dev)
+    vae.encode(img)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.iters):
+        post = vae.encode(img)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_enc = e0.elapsed_time(e1) / args.iters
+    assert torch.isfinite(post.parameters).all()
     line = {"what": f"AutoencoderKL.decode, {args.frames} frames 32x32 -> 256x256 (SURVEY.md 8 f2)", "ms": ms,
             "frames_per_s": args.frames / ms * 1e3, "algorithmic_tflop": fl / 1e12, "achieved_tflops": fl / ms / 1e9,
-            "frac_of_bf16_peak": fl / ms / 1e9 / 2500.0, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            "frac_of_bf16_peak": fl / ms / 1e9 / 2500.0, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "encode_3_images_ms": ms_enc}
     if not args.no_cpu:
         cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
         torch.set_num_threads(cores)
