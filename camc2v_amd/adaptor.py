@@ -78,8 +78,6 @@ class MultiLatentEpipolarAdaptor(nn.Module, _Prepared):
         return out
 
     def _pack(self):
-        if self.output_dim > 64:
-            raise CcvError("adaptor: the output LayerNorm kernel covers up to 64 channels")
         dev = self.latents.device
         pk = dict(in_pad=(self.embedding_dim + 63) // 64 * 64,
                   w_in=pack.pack_linear(self.proj_in.weight), b_in=_dev_f32(self.proj_in.bias),

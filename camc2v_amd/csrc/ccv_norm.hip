@@ -341,20 +341,21 @@ void launch_ln(hipStream_t st, const float* x, uint16_t* y, const float* gamma, 
     hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
 }
 
-// LayerNorm over a handful of channels (C <= 64, the adaptor's 4-channel output norm): one thread per row, fp32 in
-// (row stride ldx) and fp32 out (contiguous rows of C).
+// fp32 -> fp32 LayerNorm for the small once-per-clip tensors (the adaptor's 4-channel output norm, the Resampler's
+// 1024-wide one): one wave per row, lane-strided columns, two-pass statistics; rows are a few thousand at most.
 __global__ __launch_bounds__(256) void ln_small_kernel(const float* x, float* y, const float* gamma, const float* beta, long rows, int C,
                                                        long ldx, float eps) {
-    const long r = blockIdx.x * 256l + threadIdx.x;
+    const long r = blockIdx.x * 4l + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (r >= rows) return;
     const float* xr = x + r * ldx;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += xr[c];
-    const float mean = s / (float)C;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
-    for (int c = 0; c < C; ++c) { const float d = xr[c] - mean; q += d * d; }
-    const float rstd = rsqrtf(q / (float)C + eps);
-    for (int c = 0; c < C; ++c) y[r * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) y[r * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
 }
 
 }  // namespace
@@ -426,8 +427,8 @@ extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, co
 extern "C" int ccv_layernorm_small(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
                                    int64_t ldx, float eps, void* stream) {
     CCV_REQUIRE(x && y && gamma && beta && rows > 0, CCV_EINVAL, "ccv_layernorm_small: bad args");
-    CCV_REQUIRE(C > 0 && C <= 64 && ldx >= C, CCV_ESHAPE, "ccv_layernorm_small: C=%d must be in 1..64 and ldx >= C", C);
-    hipLaunchKernelGGL(ln_small_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, gamma, beta,
+    CCV_REQUIRE(C > 0 && ldx >= C, CCV_ESHAPE, "ccv_layernorm_small: C=%d must be positive and ldx >= C", C);
+    hipLaunchKernelGGL(ln_small_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, gamma, beta,
                        (long)rows, C, (long)ldx, eps);
     CCV_LAUNCH_CHECK("ccv_layernorm_small");
     return CCV_OK;

@@ -246,7 +246,7 @@ def concat_rows(a, b, with_bf16=False):
 
 
 def layernorm_small(x, gamma, beta, *, eps=1e-5):
-    """x fp32 [rows, >= C] (first C = gamma.numel() columns used, C <= 64) -> fp32 [rows, C]."""
+    """x fp32 [rows, >= C] (first C = gamma.numel() columns used) -> fp32 [rows, C]; for small once-per-clip tensors."""
     _dev(x, gamma, beta)
     if x.dtype != F32 or x.dim() != 2 or x.stride(1) != 1:
         raise CcvError("layernorm_small: fp32 [rows, C'] with a contiguous last dim expected")

@@ -180,8 +180,9 @@ int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const float* gamma,
 int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, const float* beta,
                   int32_t rows, int32_t C, float eps,
                   const uint16_t* addend, int32_t addend_rows, uint16_t* y2, void* stream);
-/* LayerNorm over C <= 64 channels, fp32 in (row stride ldx) -> fp32 out [rows, C]: the 4-channel output norm of
- * MultiLatentEpipolarAdaptor (model/modules/adaptors.py:180). */
+/* LayerNorm fp32 in (row stride ldx) -> fp32 out [rows, C], any C, one wave per row: the output norms of the
+ * once-per-clip modules (MultiLatentEpipolarAdaptor model/modules/adaptors.py:180: 4 channels; Resampler
+ * lvdm/modules/encoders/resampler.py:162: 1024), whose results are returned in fp32. */
 int ccv_layernorm_small(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
                         int64_t ldx, float eps, void* stream);
 

@@ -149,3 +149,22 @@ def test_adaptor_state_dict_matches_reference_manifest(golden_dir):
     from camc2v_amd.lib import CcvError
     with pytest.raises(CcvError):
         m(torch.zeros(1, 32, 4))
+
+
+def test_resampler_state_dict_matches_reference_manifest(golden_dir):
+    import json
+    import os
+
+    import pytest
+    import torch
+
+    from oracle import resampler_oracle as ro
+    from utils.utils import instantiate_from_config
+    for name, cfg in (("full", ro.FULL_CFG), ("small", ro.SMALL_CFG)):
+        man = json.load(open(os.path.join(golden_dir, f"resampler_{name}_manifest.json")))
+        with torch.device("meta" if name == "full" else "cpu"):
+            m = instantiate_from_config({"target": "lvdm.modules.encoders.resampler.Resampler", "params": dict(cfg)})
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
+    from camc2v_amd.lib import CcvError
+    with pytest.raises(CcvError):
+        m(torch.zeros(1, 9, 64))

@@ -227,3 +227,13 @@ def test_adaptor_oracle_vs_reference_fixture(golden_dir):
     mask = _unbits(fx["mask"], x.shape[1])
     _close(ao.adaptor_forward(sd, ao.SMALL_CFG, x, mask), fx["y"])
     _close(ao.adaptor_forward(sd, ao.SMALL_CFG, x, None), fx["y_nomask"])
+
+
+def test_resampler_oracle_vs_reference_fixture(golden_dir):
+    """Resampler restatement (oracle/resampler_oracle.py) against the reference's module run by
+    oracle/gen_golden_resampler.py."""
+    from oracle import resampler_oracle as ro
+    fx = dict(np.load(os.path.join(golden_dir, "resampler_small.npz")))
+    man = json.load(open(os.path.join(golden_dir, "resampler_small_manifest.json")))
+    sd = unet_oracle.seeded_state_dict(man, int(fx["seed"]), std=float(fx["std"]))
+    _close(ro.resampler_forward(sd, ro.SMALL_CFG, torch.from_numpy(fx["x"])), fx["y"])
