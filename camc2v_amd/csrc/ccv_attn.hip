@@ -274,6 +274,57 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 __device__ __attribute__((aligned(16))) unsigned char g_attn_zero_line[16];
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Online-softmax update of one 32-key x 32-query score block held as the 32x32x16 MFMA accumulator (lane = query
+// column lane&31, register i = key row (i&3) + 8 (i>>2) + 4 hh): mask -> running max -> rescale -> P = exp2(S c - m)
+// in bf16 fragments for the PV MFMA.  w = the query's 32 mask bits for this key block (ignored when all_visible,
+// which must be wave-uniform).  Instruction budget per element: v_bfe_i32 + v_bfi_b32 for the mask (the select is a
+// bit-field insert of -inf under a sign-extended mask bit), half a v_max3, half a v_pk_fma, one v_exp, half a v_pk_add.
+__device__ __forceinline__ void softmax_block32(f32x16& sa, uint32_t w, bool all_visible, int hh, float sl2, float& m_r, float& l_r,
+                                               f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
+    if (!all_visible) {
+        const int wsh = (int)(w >> (4 * hh));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int keep = __builtin_amdgcn_sbfe(wsh, (i & 3) + 8 * (i >> 2), 1);       // 0 or -1
+            float sel;   // (keep & s) | (~keep & -inf): hipcc lowers the C form to and + or, the instruction exists
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(keep), "v"(sa[i]), "v"(NEG_INF));
+            sa[i] = sel;
+        }
+    }
+    float tmax = NEG_INF;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sa[i]), sa[i + 1]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+    const float m_new = fmaxf(m_r, tmax);
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    if (!__all(m_new == m_r)) {  // some row maximum moved: rescale the running sums
+        const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
+        l_r *= alpha;
+        oa[0] = oa[0] * alpha;
+        oa[1] = oa[1] * alpha;
+        m_r = m_new;
+    }
+    const f32x2 scale2 = {sl2, sl2}, negm2 = {-m_use, -m_use};
+    f32x2 psum2 = {0.f, 0.f};
+    float pv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const f32x2 s2 = {sa[i], sa[i + 1]};
+        const f32x2 x = __builtin_elementwise_fma(s2, scale2, negm2);          // -inf -> exp2 = 0
+        const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        pv[i] = e[0];
+        pv[i + 1] = e[1];
+        psum2 = psum2 + e;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pfo[s2][j] = (__bf16)pv[8 * s2 + j];
+    l_r += psum2[0] + psum2[1];
+}
+
 // 1-D grid -> (query block, head, batch) with an XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs,
 // so giving XCD x the contiguous range [x*n/8, (x+1)*n/8) of (batch, head, query block) makes the workgroups that
 // share an L2 walk the SAME (batch, head) K/V slice (4 MB at 32x32 latents = one XCD's L2) instead of eight
@@ -445,43 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                     }
                     bf16x8 pf0[2], pf1[2];
                     auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
-                        float tmax = NEG_INF;
-                        if (__builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu))) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sa[i]);
-                        } else {
-                            const uint32_t wsh = w >> (4 * hh);
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const float sv = ((wsh >> ((i & 3) + 8 * (i >> 2))) & 1u) ? sa[i] : NEG_INF;
-                                sa[i] = sv;
-                                tmax = fmaxf(tmax, sv);
-                            }
-                        }
-                        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
-                        const float m_new = fmaxf(m_r, tmax);
-                        const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                        if (!__all(m_new == m_r)) {  // some row maximum moved: rescale the running sums
-                            const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
-                            l_r *= alpha;
-#pragma unroll
-                            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                                for (int i = 0; i < 16; ++i) oa[d][i] *= alpha;
-                            m_r = m_new;
-                        }
-                        float psum = 0.f;
-                        float pv[16];
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[i], sl2, -m_use));  // -inf -> 0
-                            psum += pv[i];
-                        }
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) pfo[s2][j] = (__bf16)pv[8 * s2 + j];
-                        l_r += psum;
+                        const bool all_visible = __builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu)) != 0;
+                        softmax_block32(sa, w, all_visible, hh, sl2, m_r, l_r, oa, pfo);
                     };
                     if (!MASKED || on0) softmax_block(sa0, mw[0][kb], m_run[0], l_run[0], oacc[0], pf0);
                     if (!MASKED || on1) softmax_block(sa1, mw[1][kb], m_run[1], l_run[1], oacc[1], pf1);
@@ -709,43 +725,8 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         }
         bf16x8 pf0[2], pf1[2];
         auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
-            float tmax = NEG_INF;
-            if (__builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu))) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sa[i]);
-            } else {
-                const uint32_t wsh = w >> (4 * hh);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float sv = ((wsh >> ((i & 3) + 8 * (i >> 2))) & 1u) ? sa[i] : NEG_INF;
-                    sa[i] = sv;
-                    tmax = fmaxf(tmax, sv);
-                }
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
-            const float m_new = fmaxf(m_r, tmax);
-            const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-            if (!__all(m_new == m_r)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
-                l_r *= alpha;
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) oa[d][i] *= alpha;
-                m_r = m_new;
-            }
-            float psum = 0.f;
-            float pv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[i], sl2, -m_use));
-                psum += pv[i];
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pfo[s2][j] = (__bf16)pv[8 * s2 + j];
-            l_r += psum;
+            const bool all_visible = __builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu)) != 0;
+            softmax_block32(sa, w, all_visible, hh, sl2, m_r, l_r, oa, pfo);
         };
         if (on0) softmax_block(sa0, mw[0], m_run[0], l_run[0], oacc[0], pf0);
         if (on1) softmax_block(sa1, mw[1], m_run[1], l_run[1], oacc[1], pf1);
