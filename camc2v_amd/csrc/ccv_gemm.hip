@@ -38,6 +38,9 @@ __device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, f
     } else if (p.act == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = gelu_erf_f(o[r]);
+    } else if (p.act == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
     }
     if (p.residual) {
         const float4 rv = *reinterpret_cast<const float4*>(p.residual + (long)m * p.ldr + n);

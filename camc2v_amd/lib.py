@@ -63,6 +63,10 @@ SIGNATURES = {
     "ccv_pack_nchw_to_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "ccv_unpack_rows_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "ccv_concat_rows": (i32, [vp, i32, vp, i32, vp, vp, i64, vp]),
+    "ccv_attn_small_fwd": (i32, [C.POINTER(CcvAttn), i32, vp]),
+    "ccv_ray_condition": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ccv_pixel_unshuffle_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "ccv_avgpool2_rows": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ccv_layernorm_small": (i32, [vp, vp, vp, vp, i64, i32, i64, f32, vp]),
     "ccv_softmax_rows": (i32, [vp, vp, i32, i32, i64, i64, vp]),
     "ccv_cast_bf16": (i32, [vp, vp, i64, vp]),

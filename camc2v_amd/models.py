@@ -4,12 +4,15 @@
 They accept the yaml ``params`` of configs/models/camcontexti2v_256.yaml / configs/baseline/*.yaml,
 build the MI355X UNet through ``unet_config``, add the camera modules natively (the reference
 monkey-patches them in, model/camcontexti2v.py:111-170) and expose ``apply_model`` / ``sample_log`` /
-``camera_condition``.  The once-per-clip feeders that need third-party weights or are ranked "next"
-in SURVEY.md section 8f (VAE, OpenCLIP, Resampler, pose encoder, latent adaptor) are not instantiated:
-their configs are kept on the object and their outputs (c_concat, c_crossattn, Pluecker features) are
-inputs of the hot path.
+``camera_condition``.  The once-per-clip feeders are not instantiated by the constructor:
+their configs are kept on the object; ``build_feeders()`` instantiates the ones built here under the reference's
+attribute names (``first_stage_model``, ``image_proj_model``, ``pose_encoder``, ``multi_cond_latent_adaptor``) so that
+the matching checkpoint slices load.  The OpenCLIP encoders need third-party code and weights and stay inputs.
 """
+import torch
+
 from . import camera
+from .config import instantiate_from_config
 from .diffusion import LatentDiffusionCore
 
 _FEEDER_KEYS = ("first_stage_config", "cond_stage_config", "img_cond_stage_config", "image_proj_stage_config",
@@ -20,12 +23,28 @@ class DynamiCrafter(LatentDiffusionCore):
     """Image-to-video base model (reference model/dynamicrafter.py, lvdm/models/ddpm3d.py:1030-1248)."""
 
     def __init__(self, unet_config, *args, **kwargs):
-        self.feeder_configs = {k: kwargs.pop(k) for k in _FEEDER_KEYS if k in kwargs}
-        self.uncond_type = kwargs.pop("uncond_type", "empty_seq")
-        self.scale_factor = kwargs.pop("scale_factor", 1.0)
+        feeder_configs = {k: kwargs.pop(k) for k in _FEEDER_KEYS if k in kwargs}
+        uncond_type = kwargs.pop("uncond_type", "empty_seq")
         kwargs.setdefault("conditioning_key", "hybrid")
         image_size = kwargs.pop("image_size", [32, 32])
         super().__init__(unet_config, *args, image_size=image_size, **kwargs)
+        self.feeder_configs, self.uncond_type = feeder_configs, uncond_type
+
+    _FEEDER_ATTRS = {"first_stage_config": "first_stage_model", "image_proj_stage_config": "image_proj_model",
+                     "pose_encoder_config": "pose_encoder", "multi_latent_adaptor": "multi_cond_latent_adaptor"}
+
+    def build_feeders(self, which=None):
+        """Instantiate the once-per-clip feeders built on the HIP kernels from the kept yaml configs (all of them, or the
+        config keys in ``which``); returns the list of attribute names created."""
+        made = []
+        for key, attr in self._FEEDER_ATTRS.items():
+            if key in self.feeder_configs and (which is None or key in which) and not hasattr(self, attr):
+                mod = instantiate_from_config(self.feeder_configs[key]).eval()
+                for p_ in mod.parameters():
+                    p_.requires_grad = False
+                setattr(self, attr, mod)
+                made.append(attr)
+        return made
 
 
 class CameraControlLVDM(DynamiCrafter):
@@ -48,6 +67,23 @@ class CameraControlLVDM(DynamiCrafter):
                                 "compression_factor", "attention_resolution", "only_on_cond_frame")}
                 unet.epipolar_origin_h = epi.get("origin_h", 256)
             unet.enable_camera_conditioning(epi, pluker=pose_cfg is not None)
+
+    def ray_condition(self, K, c2w, H, W, device=None, flip_flag=None):
+        """Ray / Pluecker embedding of relative poses (reference model/base.py:112-174)."""
+        from .pose import ray_condition
+        return ray_condition(K, c2w, H, W, device, flip_flag, self.camera_embedding)
+
+    @torch.no_grad()
+    def pose_features(self, K, w2c, cond_frame_index, H_px, W_px, trace_scale_factor=1.0):
+        """Relative poses -> embedding -> pose encoder -> the UNet's ``pluker_embedding_features`` list of
+        [b, C_i, f, h_i, w_i] (reference model/camcontexti2v.py:531-537, 556-561)."""
+        enc = getattr(self, "pose_encoder", None)
+        if enc is None:
+            raise RuntimeError("pose_features: call build_feeders() first (needs pose_encoder_config)")
+        rel = camera.relative_c2w(w2c, cond_frame_index, trace_scale_factor)
+        emb = self.ray_condition(K.float(), rel, H_px, W_px)
+        b = emb.shape[0]
+        return [f_.reshape(b, -1, *f_.shape[1:]).permute(0, 2, 1, 3, 4).contiguous() for f_ in enc(emb)]
 
     def camera_condition(self, K, w2c, cond_frame_index, H_px, W_px, pluker_features=None,
                          trace_scale_factor=1.0, generator=None, noise=None):

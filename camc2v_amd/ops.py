@@ -15,7 +15,7 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 GATHER_LINEAR, GATHER_CONV3X3, GATHER_TCONV3 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 
 # 0: V^T fragments through ds_read_b64_tr_b16; 1: V transposed while staging (fallback)
 ATTN_VARIANT = 0
@@ -243,6 +243,57 @@ def concat_rows(a, b, with_bf16=False):
     out16 = torch.empty((rows, ca + cb), dtype=BF16, device=a.device) if with_bf16 else None
     check(lib().ccv_concat_rows(_ptr(a), ca, _ptr(b), cb, _ptr(out), _ptr(out16), rows, _stream()), "ccv_concat_rows")
     return (out, out16) if with_bf16 else out
+
+
+def attention_small(q, k, v, *, B, inner, H, T, head_dim, q_str, k_str, v_str, out=None, o_str=None, scale=None):
+    """Self-attention over T <= 16 tokens, any head width (multiple of 8, <= 256); strides as in ``attention``."""
+    _dev(q, k, v, out)
+    for t in (q, k, v):
+        if t.dtype != BF16:
+            raise CcvError("attention_small: q/k/v must be bf16")
+    if out is None:
+        out = torch.empty((B * T, H * head_dim), dtype=BF16, device=q.device)
+        o_str = ((T * H * head_dim) * inner, T * H * head_dim, H * head_dim)
+    p = CcvAttn()
+    p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(out)
+    p.q_bso, p.q_bsi, p.q_ls = q_str
+    p.k_bso, p.k_bsi, p.k_ls = k_str
+    p.v_bso, p.v_bsi, p.v_ls = v_str
+    p.o_bso, p.o_bsi, p.o_ls = o_str
+    p.B, p.inner, p.H, p.Lq, p.Lk = B, inner, H, T, T
+    p.scale = scale if scale is not None else 1.0 / math.sqrt(float(head_dim))
+    check(lib().ccv_attn_small_fwd(C.byref(p), head_dim, _stream()), "ccv_attn_small_fwd")
+    return out
+
+
+def ray_condition(K, c2w, H, W, plucker=True):
+    """K [B,V,3,3], c2w [B,V,4,4] -> fp32 [B, 6, V, H, W] (reference model/base.py:112-174)."""
+    _dev(K, c2w)
+    K, c2w = K.float().contiguous(), c2w.float().contiguous()
+    B, V = K.shape[:2]
+    out = torch.empty((B, 6, V, H, W), dtype=F32, device=K.device)
+    check(lib().ccv_ray_condition(_ptr(K), _ptr(c2w), _ptr(out), B, V, H, W, int(plucker), _stream()), "ccv_ray_condition")
+    return out
+
+
+def pixel_unshuffle_rows(x, r):
+    """x fp32 [n, c, H, W] -> bf16 token rows [(n H/r W/r), c r^2] in torch.nn.PixelUnshuffle channel order."""
+    _dev(x)
+    x = x.float().contiguous()
+    n, c, H, W = x.shape
+    y = torch.empty((n * (H // r) * (W // r), c * r * r), dtype=BF16, device=x.device)
+    check(lib().ccv_pixel_unshuffle_rows(_ptr(x), _ptr(y), n, c, H, W, r, _stream()), "ccv_pixel_unshuffle_rows")
+    return y
+
+
+def avgpool2_rows(x, n, H, W):
+    """fp32 token rows [(n H W), C] -> [(n H/2 W/2), C] (nn.AvgPool2d(2))."""
+    _dev(x)
+    if x.dtype != F32 or not x.is_contiguous() or x.shape[0] != n * H * W:
+        raise CcvError("avgpool2_rows: contiguous fp32 rows [(n H W), C] expected")
+    y = torch.empty((n * (H // 2) * (W // 2), x.shape[1]), dtype=F32, device=x.device)
+    check(lib().ccv_avgpool2_rows(_ptr(x), _ptr(y), n, H, W, x.shape[1], _stream()), "ccv_avgpool2_rows")
+    return y
 
 
 def layernorm_small(x, gamma, beta, *, eps=1e-5):

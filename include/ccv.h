@@ -86,7 +86,7 @@ typedef struct CcvGemm {
                              * encoder's Downsample (lvdm/modules/networks/ae_modules.py:106-110) */
     int32_t frames, hw;     /* gather 2: frames per clip, pixels per frame */
     int32_t rows_per_batch; /* bias2 row = m / rows_per_batch */
-    int32_t act;            /* 0 none, 1 SiLU, 2 GELU(erf) */
+    int32_t act;            /* 0 none, 1 SiLU, 2 GELU(erf), 3 ReLU */
     int32_t geglu;          /* 0/1 */
     int32_t out_f32;        /* 0: C is bf16, 1: C is fp32 */
     float alpha;
@@ -156,6 +156,10 @@ typedef struct CcvAttn {
                             64-query groups upwards and the tiled masked kernel below that) */
 } CcvAttn;
 int ccv_attn_fwd(const CcvAttn* p, void* stream);
+/* Self-attention over Lq = Lk <= 16 tokens with an arbitrary head width (multiple of 8, <= 256): the temporal blocks of
+ * CameraPoseEncoder (model/modules/camera_pose_encoder.py:15-158; heads of 40 / 80 / 160 channels).  Uses q/k/v/o with
+ * their strides, B, inner, H, Lq, scale of CcvAttn; the head h of a token starts at column h * head_dim.  No masks. */
+int ccv_attn_small_fwd(const CcvAttn* p, int32_t head_dim, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * GroupNorm(32 groups) (+SiLU) over token-major activations, fp32 statistics.
@@ -201,6 +205,14 @@ int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out, int32_t c,
  * same rows rounded to bf16, the form the ResBlock's 1x1 skip convolution consumes as a GEMM operand. */
 int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, uint16_t* out_bf16,
                     int64_t rows, void* stream);
+/* Once-per-clip camera feeders (model/base.py:112-174, model/modules/camera_pose_encoder.py:361-376).
+ * ccv_ray_condition: K [B,V,3,3], c2w [B,V,4,4] fp32 -> out [B,6,V,H,W] fp32, (o x d | d) when plucker != 0 else (o | d).
+ * ccv_pixel_unshuffle_rows: x [n,c,H,W] fp32 -> token rows [(n H/r W/r), c r^2] bf16 (torch.nn.PixelUnshuffle order).
+ * ccv_avgpool2_rows: token rows [(n H W), C] fp32 -> [(n H/2 W/2), C] fp32 (nn.AvgPool2d(2)). */
+int ccv_ray_condition(const float* K, const float* c2w, float* out, int32_t B, int32_t V, int32_t H, int32_t W,
+                      int32_t plucker, void* stream);
+int ccv_pixel_unshuffle_rows(const float* x, uint16_t* y, int32_t n, int32_t c, int32_t H, int32_t W, int32_t r, void* stream);
+int ccv_avgpool2_rows(const float* x, float* y, int32_t n, int32_t H, int32_t W, int32_t C, void* stream);
 /* Row softmax fp32 [rows, ldx] -> bf16 [rows, ldy] over L columns: the single-head, 512-wide attention of the first-stage
  * decoder (lvdm/modules/networks/ae_modules.py:66-70) runs as GEMM (QK^T, alpha = C^-1/2) -> this -> GEMM (P V). */
 int ccv_softmax_rows(const float* x, uint16_t* y, int32_t rows, int32_t L, int64_t ldx, int64_t ldy, void* stream);

@@ -237,3 +237,13 @@ def test_resampler_oracle_vs_reference_fixture(golden_dir):
     man = json.load(open(os.path.join(golden_dir, "resampler_small_manifest.json")))
     sd = unet_oracle.seeded_state_dict(man, int(fx["seed"]), std=float(fx["std"]))
     _close(ro.resampler_forward(sd, ro.SMALL_CFG, torch.from_numpy(fx["x"])), fx["y"])
+
+
+def test_ray_condition_oracle_vs_reference_fixture(golden_dir):
+    """ray_condition restatement against the reference's method (oracle/gen_golden_pose.py), both embeddings."""
+    from oracle import pose_oracle as po
+    fx = dict(np.load(os.path.join(golden_dir, "pose_small.npz")))
+    K, c2w = torch.from_numpy(fx["K"]), torch.from_numpy(fx["c2w"])
+    H, W = fx["plucker"].shape[-2:]
+    _close(po.ray_condition(K, c2w, H, W, plucker=True), fx["plucker"], 1e-5)
+    _close(po.ray_condition(K, c2w, H, W, plucker=False), fx["ray"], 1e-5)
