@@ -31,6 +31,26 @@ def camcontexti2v_256(unet_params=None):
     }
 
 
+# once-per-clip feeders built on the HIP kernels (yaml first_stage_config / image_proj_stage_config /
+# pose_encoder_config / multi_latent_adaptor, configs/models/camcontexti2v_256.yaml:74-151); instantiated by
+# ``model.build_feeders()``
+FEEDERS_256 = dict(
+    first_stage_config={"target": "lvdm.models.autoencoder.AutoencoderKL", "params": dict(
+        embed_dim=4, monitor="val/rec_loss", lossconfig={"target": "torch.nn.Identity"},
+        ddconfig=dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                      num_res_blocks=2, attn_resolutions=[], dropout=0.0))},
+    image_proj_stage_config={"target": "lvdm.modules.encoders.resampler.Resampler", "params": dict(
+        dim=1024, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=1024, ff_mult=4,
+        video_length=16, use_timestep_emb=True)},
+    pose_encoder_config={"target": "model.modules.camera_pose_encoder.CameraPoseEncoder", "params": dict(
+        downscale_factor=8, channels=[320, 640, 1280, 1280], nums_rb=2, cin=384, ksize=1, sk=True, use_conv=False,
+        compression_factor=1, temporal_attention_nhead=8, attention_block_types=["Temporal_Self"],
+        temporal_position_encoding=True, temporal_position_encoding_max_len=16)},
+    multi_latent_adaptor={"target": "model.modules.adaptors.MultiLatentEpipolarAdaptor", "params": dict(
+        query_dim=512, num_queries=1024, video_length=16, embedding_dim=4, output_dim=4, depth=12, checkpoint=True,
+        timestep_embedding_type="sinusoidal_embedded", use_plucker_embedding=False)},
+)
+
 # generation kwargs wired by the reference launcher (CamContextI2V/02_generate_videos.py:318-327)
 GENERATION_KWARGS = dict(ddim_steps=25, eta=1.0, unconditional_guidance_scale=7.5,
                          timestep_spacing="uniform_trailing", guidance_rescale=0.7, enable_camera_condition=True)
