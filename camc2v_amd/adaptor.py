@@ -124,9 +124,14 @@ class MultiLatentEpipolarAdaptor(nn.Module, _Prepared):
         lat = self.latents.detach().float().expand(B, Lq, C).reshape(B * Lq, C).contiguous()
         mk = {}
         if mask is not None and self.use_mask:
-            if mask.dtype != torch.bool or tuple(mask.shape) != (B, Lq, Lk):
-                raise CcvError(f"adaptor mask must be bool [{B}, {Lq}, {Lk}]")
-            mp = ops.pack_mask(mask)
+            if isinstance(mask, ops.MaskPack):        # already bit-packed (ops.epipolar_mask_bits / ops.pack_mask)
+                mp = mask
+                if mp[0].shape[0] != B or mp[0].shape[1] != Lq or mp[0].shape[2] * 32 < Lk:
+                    raise CcvError(f"adaptor: packed mask {tuple(mp[0].shape)} does not cover [{B}, {Lq}, {Lk}]")
+            else:
+                if mask.dtype != torch.bool or tuple(mask.shape) != (B, Lq, Lk):
+                    raise CcvError(f"adaptor mask must be bool [{B}, {Lq}, {Lk}]")
+                mp = ops.pack_mask(mask)
             mk = dict(mask_bits=mp[0], tile_flags=mp[1], mask_nb=B, wave_bits=mp.wave_bits, group_order=mp.group_order)
         for lp in pk["layers"]:
             q = ops.gemm(ops.cast_bf16(lat), lp["w_q"])

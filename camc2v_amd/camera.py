@@ -42,6 +42,23 @@ def pairwise_fundamental(K, rel_c2w, perturb_zero_translation=True, generator=No
     return K_inv.transpose(-1, -2) @ E @ K_inv
 
 
+def conditional_fundamental(K, w2c, w2c_context, cond_frame_index=None):
+    """Fundamental matrices between the T target frames and the context frames (reference
+    compute_conditional_epipolar_mask, model/camcontexti2v.py:493-516): K [b,t,3,3] target intrinsics, w2c [b,t,4,4],
+    w2c_context [b,n,4,4]; with cond_frame_index the conditioning frame's pose is prepended to the context poses.
+    Pair (t, c) uses inv(c2w_ctx[c]) @ c2w[t]; E = t x R; F = K_t^-T E K_t^-1.  Returns F [b, t, n(+1), 3, 3]."""
+    c2w = torch.linalg.inv(w2c.float())
+    ctx = torch.linalg.inv(w2c_context.float())
+    if cond_frame_index is not None:
+        b = c2w.shape[0]
+        ctx = torch.cat([c2w[torch.arange(b, device=c2w.device), cond_frame_index].unsqueeze(1), ctx], 1)
+    rel = torch.linalg.inv(ctx)[:, None] @ c2w[:, :, None]                 # [b, t, c, 4, 4]
+    R, t = rel[..., :3, :3], rel[..., :3, 3:4]
+    E = torch.cross(t.expand_as(R), R, dim=-2)
+    K_inv = torch.linalg.inv(K.float())[:, :, None]
+    return K_inv.transpose(-1, -2) @ E @ K_inv
+
+
 def epipolar_masks_packed(F, T, H_px, W_px, attention_resolution=(8, 4, 2, 1), patch_order=True):
     """F [b,T,T,3,3] -> {8*ds: (bits int32 [b, L, L/32], flags uint8 [b, L/128, L/64], perm, wave_bits int32 [b, L/64, L/1024],
     group_order int32 [b, L/64])},

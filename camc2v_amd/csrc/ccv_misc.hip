@@ -216,10 +216,10 @@ __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* f
 // F [B, T, T, 3, 3] -> packed mask words; query (t1,p1) row, key (t2,p2) column.
 // Arithmetic mirrors model/camcontexti2v.py:229-239 in fp32 without FMA contraction:
 //   l = F x1; l /= ||l_xy||; visible <=> |l . x2| < d*sqrt(2)/2.
-__global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int T, int H, int W, float d,
+__global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int T, int Tk, int H, int W, float d,
                                      int words, int ktiles, int64_t nwords_total, int perm_w) {
 #pragma clang fp contract(off)
-    const int HW = H * W, L = T * HW;
+    const int HW = H * W, L = T * HW, Lk = Tk * HW;   // L query rows (T frames), Lk key columns (Tk frames)
     const float thr = d * 0.70710678118654752440f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords_total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -235,11 +235,11 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
         int t2_cached = -1;
         float l0 = 0.f, l1 = 0.f, l2 = 0.f;
         for (int j = 0; j < 32; ++j) {
-            if (w * 32 + j >= L) break;
+            if (w * 32 + j >= Lk) break;
             const int key = ccv_patch_row(w * 32 + j, HW, perm_w);
             const int t2 = key / HW, p2 = key % HW;
             if (t2 != t2_cached) {
-                const float* f = F + ((b * T + t1) * T + t2) * 9;
+                const float* f = F + ((b * T + t1) * Tk + t2) * 9;
                 const float a0 = f[0] * x1 + f[1] * y1 + f[2];
                 const float a1 = f[3] * x1 + f[4] * y1 + f[5];
                 const float a2 = f[6] * x1 + f[7] * y1 + f[8];
@@ -404,16 +404,26 @@ extern "C" int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags
     return CCV_OK;
 }
 
+extern "C" int ccv_epipolar_mask_bits_rect(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int32_t B, int32_t Tq,
+                                           int32_t Tk, int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream);
+
 extern "C" int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int32_t B, int32_t T,
                                       int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream) {
     CCV_REQUIRE(F && bits && B > 0 && T > 0 && H > 0 && W > 0 && downsample > 0, CCV_EINVAL, "ccv_epipolar_mask_bits: bad args");
     CCV_REQUIRE(!patch_order || (W % 8 == 0 && H % 4 == 0), CCV_ESHAPE, "ccv_epipolar_mask_bits: patch order needs W %% 8 == 0 and H %% 4 == 0");
-    const int L = T * H * W;
-    const int words = (L + 31) / 32, ktiles = (L + 63) / 64;
+    return ccv_epipolar_mask_bits_rect(F, bits, flags, wave_bits, B, T, T, H, W, downsample, patch_order, stream);
+}
+
+extern "C" int ccv_epipolar_mask_bits_rect(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int32_t B, int32_t Tq,
+                                           int32_t Tk, int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream) {
+    CCV_REQUIRE(F && bits && B > 0 && Tq > 0 && Tk > 0 && H > 0 && W > 0 && downsample > 0, CCV_EINVAL, "ccv_epipolar_mask_bits_rect: bad args");
+    CCV_REQUIRE(!patch_order || (W % 8 == 0 && H % 4 == 0), CCV_ESHAPE, "ccv_epipolar_mask_bits_rect: patch order needs W %% 8 == 0 and H %% 4 == 0");
+    const int L = Tq * H * W, Lk = Tk * H * W;
+    const int words = (Lk + 31) / 32, ktiles = (Lk + 63) / 64;
     const int64_t n = (int64_t)B * L * words;
-    hipLaunchKernelGGL(epipolar_bits_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), F, bits, flags, wave_bits, T, H, W,
+    hipLaunchKernelGGL(epipolar_bits_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), F, bits, flags, wave_bits, Tq, Tk, H, W,
                        (float)downsample, words, ktiles, n, patch_order ? W : 0);
-    CCV_LAUNCH_CHECK("ccv_epipolar_mask_bits");
+    CCV_LAUNCH_CHECK("ccv_epipolar_mask_bits_rect");
     return CCV_OK;
 }
 

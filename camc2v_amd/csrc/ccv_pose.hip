@@ -132,6 +132,39 @@ __global__ __launch_bounds__(128) void attn_small_kernel(const CcvAttn p, int D)
     }
 }
 
+// Direct 3x3x3 convolution (padding 1) of a few channels: x [B, Cin, T, H, W] fp32 -> y [B, Cout, T, H, W] fp32 (+ bias), optionally
+// added to a per-clip image `add` [B, Cout, H, W] broadcast over T: the zero-initialised latent projection behind the
+// context-frame adaptor (model/camcontexti2v.py:81-84, 368-373).  Cin, Cout <= 8; one thread per output voxel.
+__global__ void conv3d_small_kernel(const float* x, const float* w, const float* bias, const float* add, float* y, int B, int Cin, int Cout,
+                                    int T, int H, int W) {
+    const int64_t n = (int64_t)B * T * H * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % W), py = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % T), b = (int)(i / ((int64_t)W * H * T));
+        float acc[8];
+        for (int co = 0; co < Cout; ++co) acc[co] = bias ? bias[co] : 0.f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int dt = 0; dt < 3; ++dt) {
+                const int tt = t + dt - 1;
+                if (tt < 0 || tt >= T) continue;
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = py + dy - 1;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int xx = px + dx - 1;
+                        if (xx < 0 || xx >= W) continue;
+                        const float v = x[((((int64_t)b * Cin + ci) * T + tt) * H + yy) * W + xx];
+                        for (int co = 0; co < Cout; ++co) acc[co] += v * w[(((co * Cin + ci) * 3 + dt) * 3 + dy) * 3 + dx];
+                    }
+                }
+            }
+        for (int co = 0; co < Cout; ++co) {
+            float o = acc[co];
+            if (add) o += add[(((int64_t)b * Cout + co) * H + py) * W + px];
+            y[((((int64_t)b * Cout + co) * T + t) * H + py) * W + px] = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ccv_ray_condition(const float* K, const float* c2w, float* out, int32_t B, int32_t V, int32_t H, int32_t W,
@@ -171,5 +204,15 @@ extern "C" int ccv_attn_small_fwd(const CcvAttn* pp, int32_t head_dim, void* str
     const long items = (long)p.B * p.H;
     hipLaunchKernelGGL(attn_small_kernel, dim3((unsigned)((items + 1) / 2)), dim3(128), 0, static_cast<hipStream_t>(stream), p, head_dim);
     CCV_LAUNCH_CHECK("ccv_attn_small_fwd");
+    return CCV_OK;
+}
+
+extern "C" int ccv_conv3d_small(const float* x, const float* w, const float* bias, const float* add, float* y, int32_t B, int32_t Cin,
+                                int32_t Cout, int32_t T, int32_t H, int32_t W, void* stream) {
+    CCV_REQUIRE(x && w && y && B > 0 && T > 0 && H > 0 && W > 0, CCV_EINVAL, "ccv_conv3d_small: bad args");
+    CCV_REQUIRE(Cin > 0 && Cin <= 8 && Cout > 0 && Cout <= 8, CCV_ESHAPE, "ccv_conv3d_small: 1..8 channels (got %d -> %d)", Cin, Cout);
+    hipLaunchKernelGGL(conv3d_small_kernel, grid1d_pose((int64_t)B * T * H * W), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias, add, y,
+                       B, Cin, Cout, T, H, W);
+    CCV_LAUNCH_CHECK("ccv_conv3d_small");
     return CCV_OK;
 }

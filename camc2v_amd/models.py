@@ -114,6 +114,36 @@ class CamContextI2V(CameraControlLVDM):
         super().__init__(*args, **kwargs)
         self.multi_cond_strategy = multi_cond_strategy
         self.use_zero_conv_latent_input = use_zero_conv_latent_input
+        if use_zero_conv_latent_input:      # zero-initialised latent projection (reference camcontexti2v.py:81-84)
+            self.multi_cond_in_projection = torch.nn.Conv3d(4, 4, kernel_size=3, stride=1, padding=1)
+            torch.nn.init.constant_(self.multi_cond_in_projection.weight, 0.0)
+            torch.nn.init.constant_(self.multi_cond_in_projection.bias, 0.0)
+
+    @torch.no_grad()
+    def context_concat(self, z_cond, z_context, K, w2c, w2c_context, cond_frame_index):
+        """The ``c_concat`` latents of strategy 'token_concat_latent_epipolar' (reference camcontexti2v.py:334-377 with
+        use_zero_conv_latent_input, without cross normalisation): z_cond [b, 4, h, w] latent of the conditioning frame,
+        z_context [b, 4, n, h, w] latents of the extra context frames, K [b,t,3,3], w2c [b,t,4,4], w2c_context [b,n,4,4].
+        Adaptor over [conditioning ; context] tokens with the target x context epipolar mask -> Conv3d(4,4,3) -> +
+        conditioning latent on every frame.  Returns fp32 [b, 4, t, h, w]."""
+        from . import ops
+        adaptor = getattr(self, "multi_cond_latent_adaptor", None)
+        if adaptor is None:
+            raise RuntimeError("context_concat: call build_feeders() first (needs multi_latent_adaptor)")
+        b, c, h, w = z_cond.shape
+        t = w2c.shape[1]
+        z_inp = torch.cat([z_cond[:, :, None], z_context], 2)                         # b c (1+n) h w
+        tokens = z_inp.permute(0, 2, 3, 4, 1).reshape(b, -1, c).contiguous()           # 'B D C H W -> B (C H W) D'
+        mask = None
+        if adaptor.use_mask:
+            F = camera.conditional_fundamental(K, w2c, w2c_context, cond_frame_index)
+            mask = ops.epipolar_mask_bits(F, t, h, w, 8)
+        lat = adaptor(tokens, mask)                                                    # b (t h w) c
+        x = lat.reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3).contiguous()             # b c t h w
+        if not self.use_zero_conv_latent_input:
+            return x
+        proj = self.multi_cond_in_projection
+        return ops.conv3d_small(x, proj.weight, proj.bias, add=z_cond)
 
 
 class CamI2V(CameraControlLVDM):

@@ -296,6 +296,24 @@ def avgpool2_rows(x, n, H, W):
     return y
 
 
+def conv3d_small(x, weight, bias=None, add=None):
+    """x fp32 [B, Cin, T, H, W], weight [Cout, Cin, 3, 3, 3] (Cin, Cout <= 8), padding 1, + bias, + add [B, Cout, H, W]
+    broadcast over T."""
+    _dev(x, weight, bias, add)
+    x, weight = x.float().contiguous(), weight.float().contiguous()
+    B, Cin, T, H, W = x.shape
+    Cout = weight.shape[0]
+    if tuple(weight.shape) != (Cout, Cin, 3, 3, 3):
+        raise CcvError("conv3d_small: weight must be [Cout, Cin, 3, 3, 3]")
+    bias = bias.float().contiguous() if bias is not None else None
+    add = add.float().contiguous() if add is not None else None
+    if add is not None and tuple(add.shape) != (B, Cout, H, W):
+        raise CcvError("conv3d_small: add must be [B, Cout, H, W]")
+    y = torch.empty((B, Cout, T, H, W), dtype=F32, device=x.device)
+    check(lib().ccv_conv3d_small(_ptr(x), _ptr(weight), _ptr(bias), _ptr(add), _ptr(y), B, Cin, Cout, T, H, W, _stream()), "ccv_conv3d_small")
+    return y
+
+
 def layernorm_small(x, gamma, beta, *, eps=1e-5):
     """x fp32 [rows, >= C] (first C = gamma.numel() columns used) -> fp32 [rows, C]; for small once-per-clip tensors."""
     _dev(x, gamma, beta)
@@ -414,14 +432,17 @@ def pack_mask(mask, perm=None):
 
 
 def epipolar_mask_bits(F, T, H, W, downsample, patch_order=False):
-    """F [B, T, T, 3, 3] fp32 -> packed epipolar mask (bits, flags) for an HxW feature map."""
+    """F [B, T, Tk, 3, 3] fp32 -> packed epipolar mask (bits, flags) for an HxW feature map: T query frames x Tk key frames
+    (Tk = T for the UNet's temporal blocks; target frames x context frames for the adaptor)."""
     _dev(F)
     F = F.contiguous().float()
-    B = F.shape[0]
-    L = T * H * W
-    bits = torch.empty((B, L, (L + 31) // 32), dtype=torch.int32, device=F.device)
-    flags = torch.zeros((B, (L + 127) // 128, (L + 63) // 64), dtype=torch.uint8, device=F.device)
-    wbits = torch.zeros((B, (L + 63) // 64, ((L + 31) // 32 + 31) // 32), dtype=torch.int32, device=F.device)
-    check(lib().ccv_epipolar_mask_bits(_ptr(F), _ptr(bits), _ptr(flags), _ptr(wbits), B, T, H, W, downsample, int(patch_order),
-                                       _stream()), "ccv_epipolar_mask_bits")
+    B, Tk = F.shape[0], F.shape[2]
+    if F.shape[1] != T:
+        raise CcvError(f"epipolar_mask_bits: F has {F.shape[1]} query frames, expected {T}")
+    L, Lk = T * H * W, Tk * H * W
+    bits = torch.empty((B, L, (Lk + 31) // 32), dtype=torch.int32, device=F.device)
+    flags = torch.zeros((B, (L + 127) // 128, (Lk + 63) // 64), dtype=torch.uint8, device=F.device)
+    wbits = torch.zeros((B, (L + 63) // 64, ((Lk + 31) // 32 + 31) // 32), dtype=torch.int32, device=F.device)
+    check(lib().ccv_epipolar_mask_bits_rect(_ptr(F), _ptr(bits), _ptr(flags), _ptr(wbits), B, T, Tk, H, W, downsample, int(patch_order),
+                                            _stream()), "ccv_epipolar_mask_bits_rect")
     return MaskPack(bits, flags, wbits, attn_group_order(wbits))

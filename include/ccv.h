@@ -213,6 +213,11 @@ int ccv_ray_condition(const float* K, const float* c2w, float* out, int32_t B, i
                       int32_t plucker, void* stream);
 int ccv_pixel_unshuffle_rows(const float* x, uint16_t* y, int32_t n, int32_t c, int32_t H, int32_t W, int32_t r, void* stream);
 int ccv_avgpool2_rows(const float* x, float* y, int32_t n, int32_t H, int32_t W, int32_t C, void* stream);
+/* 3x3x3 convolution (padding 1) over [B, Cin, T, H, W] fp32 with Cin, Cout <= 8, + bias, + optional image `add`
+ * [B, Cout, H, W] broadcast over T: the latent projection + residual after the context-frame adaptor
+ * (nn.Conv3d(4, 4, 3, 1, 1), model/camcontexti2v.py:81-84, 368-373). */
+int ccv_conv3d_small(const float* x, const float* w, const float* bias, const float* add, float* y, int32_t B, int32_t Cin,
+                     int32_t Cout, int32_t T, int32_t H, int32_t W, void* stream);
 /* Row softmax fp32 [rows, ldx] -> bf16 [rows, ldy] over L columns: the single-head, 512-wide attention of the first-stage
  * decoder (lvdm/modules/networks/ae_modules.py:66-70) runs as GEMM (QK^T, alpha = C^-1/2) -> this -> GEMM (P V). */
 int ccv_softmax_rows(const float* x, uint16_t* y, int32_t rows, int32_t L, int64_t ldx, int64_t ldy, void* stream);
@@ -256,6 +261,11 @@ int ccv_pack_mask(const uint8_t* mask, uint32_t* bits, uint8_t* flags, uint32_t*
                   int32_t B, int32_t Lq, int32_t Lk, int32_t perm_hw, int32_t perm_w, void* stream);
 int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
                            int32_t B, int32_t T, int32_t H, int32_t W, int32_t downsample, int32_t patch_order, void* stream);
+/* Same with Tq query frames and Tk key frames, F [B, Tq, Tk, 3, 3]: rows (Tq H W) x bit columns (Tk H W) -- the
+ * target-frame x context-frame mask of the adaptor (compute_conditional_epipolar_mask, model/camcontexti2v.py:493-521). */
+int ccv_epipolar_mask_bits_rect(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
+                                int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t W, int32_t downsample, int32_t patch_order,
+                                void* stream);
 /* Schedule of the sparse attention kernel (once per clip, after the mask was packed on the same stream):
  * order[b][r] = index of the 64-query group with the r-th largest popcount of its wave_bits row (ties: lower index first).
  * wave_bits [B, ngroups, wave_words], order [B, ngroups] int32; ngroups <= 8192. */

@@ -54,7 +54,38 @@ def main():
         err = (po.ray_condition(K, c2w, H, W, plucker=(mode == "plucker")) - y).abs().max().item()
         assert err < 1e-5, (mode, err)
         out[mode] = y.numpy()
-    np.savez_compressed(os.path.join(args.out, "pose_small.npz"), K=K.numpy(), c2w=c2w.numpy(), plucker=out["plucker"], ray=out["ray"])
+    # target-frame x context-frame epipolar mask: the sub-functions compute_conditional_epipolar_mask
+    # (model/camcontexti2v.py:493-521) calls, composed in its order (the method itself reads a data batch through
+    # super().get_input and cannot be called on a stub)
+    import model.camcontexti2v as cc
+    from einops import rearrange, repeat
+    stub = types.SimpleNamespace(epipolar_config=types.SimpleNamespace(
+        apply_epipolar_soft_mask=False, epipolar_hybrid_attention=False, epipolar_hybrid_attention_v2=False,
+        only_self_pixel_on_current_frame=False, current_frame_as_register_token=False))
+    Tt, px = 4, 64
+    Kc = torch.tensor([[40.0, 0, 32.0], [0, 44.0, 30.0], [0, 0, 1.0]]).repeat(1, Tt, 1, 1)
+    w2c_t = geo.synthetic_trajectory(1, Tt)
+    w2c_ctx = geo.synthetic_trajectory(1, 8)[:, [5, 7]]
+    w2c_ctx[0, :, :3, 3] += 0.2 * torch.randn(2, 3, generator=g)
+    cond_idx = torch.tensor([1])
+    c2w_t, c2w_c = w2c_t.inverse(), w2c_ctx.inverse()
+    c2w_c = torch.cat((c2w_t[torch.arange(1), cond_idx].unsqueeze(1), c2w_c), dim=1)
+    rel = CameraControlLVDM.get_pairwise_relative_pose(stub, c2w_c, c2w_t)
+    rel = rearrange(rel, 'B T C H W -> B C T H W')
+    R, t = rel[..., :3, :3], rel[..., :3, 3:4]
+    Cn = R.shape[2]
+    Kr = repeat(Kc, 'B T H W -> B (T C) H W', C=Cn)
+    Fc = cc.CamContextI2V.get_fundamental_matrix(stub, Kr, rearrange(R, 'B T C H W -> B (T C) H W'), rearrange(t, 'B T C H W -> B (T C) H W'))
+    Fc = rearrange(Fc, 'B (T C) H W -> B T C H W', C=Cn)
+    cmask = cc.CamContextI2V.get_epipolar_mask(stub, Fc, Tt, px // 8, px // 8, 8, True)
+    Fo = geo.conditional_fundamental(Kc, w2c_t, w2c_ctx, cond_idx)
+    assert (Fo - Fc).abs().max().item() < 1e-4 * Fc.abs().max().item()
+    assert torch.equal(geo.epipolar_mask(Fc, px // 8, px // 8, 8), cmask)
+    np.savez_compressed(os.path.join(args.out, "pose_small.npz"), K=K.numpy(), c2w=c2w.numpy(), plucker=out["plucker"], ray=out["ray"],
+                        cond_K=Kc.numpy(), cond_w2c=w2c_t.numpy(), cond_w2c_ctx=w2c_ctx.numpy(), cond_index=cond_idx.numpy(),
+                        cond_F=Fc.numpy(), cond_mask=np.packbits(cmask.numpy(), axis=-1, bitorder="little"),
+                        cond_mask_shape=np.array(cmask.shape))
+    print("conditional mask", tuple(cmask.shape), "density %.3f" % cmask.float().mean().item())
     print("pose_small: ray_condition", out["plucker"].shape, "oracle agrees")
 
 

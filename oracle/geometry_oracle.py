@@ -94,6 +94,18 @@ def camera_masks(K, w2c, cond_frame_index, H_px, W_px, resolutions=(8, 4, 2, 1),
     return F, masks
 
 
+def conditional_fundamental(K, w2c, w2c_context, cond_frame_index=None):
+    """Target-frame x context-frame fundamental matrices (compute_conditional_epipolar_mask, camcontexti2v.py:493-516):
+    context poses = [conditioning frame's pose ; w2c_context]; pair (t, c) = inv(c2w_ctx[c]) @ c2w[t]; F = K_t^-T (t x R) K_t^-1.
+    Returns [b, t, c, 3, 3]."""
+    c2w = torch.linalg.inv(w2c.float())
+    ctx = torch.linalg.inv(w2c_context.float())
+    if cond_frame_index is not None:
+        ctx = torch.cat([c2w[torch.arange(c2w.shape[0]), cond_frame_index].unsqueeze(1), ctx], 1)
+    rel = torch.linalg.inv(ctx)[:, None] @ c2w[:, :, None]
+    return fundamental_matrix(K.float()[:, :, None], rel[..., :3, :3], rel[..., :3, 3:4])
+
+
 def pack_mask_bits(mask):
     """bool [..., L] -> uint8 [..., ceil(L/8)] little-endian bit order (bit j of byte i = column 8i+j)."""
     return np.packbits(mask.numpy().astype(np.uint8), axis=-1, bitorder="little")

@@ -247,3 +247,14 @@ def test_ray_condition_oracle_vs_reference_fixture(golden_dir):
     H, W = fx["plucker"].shape[-2:]
     _close(po.ray_condition(K, c2w, H, W, plucker=True), fx["plucker"], 1e-5)
     _close(po.ray_condition(K, c2w, H, W, plucker=False), fx["ray"], 1e-5)
+
+
+def test_conditional_epipolar_mask_oracle_vs_reference_fixture(golden_dir):
+    """Target x context fundamental matrices and mask (the adaptor's mask) against the reference's sub-functions."""
+    fx = dict(np.load(os.path.join(golden_dir, "pose_small.npz")))
+    F = geometry_oracle.conditional_fundamental(torch.from_numpy(fx["cond_K"]), torch.from_numpy(fx["cond_w2c"]),
+                                                torch.from_numpy(fx["cond_w2c_ctx"]), torch.from_numpy(fx["cond_index"]))
+    _close(F, fx["cond_F"], 1e-4)
+    shape = tuple(int(v) for v in fx["cond_mask_shape"])
+    ref = _unbits(fx["cond_mask"], shape[-1])
+    assert torch.equal(geometry_oracle.epipolar_mask(torch.from_numpy(fx["cond_F"]), 8, 8, 8), ref)

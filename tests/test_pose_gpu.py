@@ -128,3 +128,69 @@ def test_model_level_pose_features():
     feats = model.pose_features(K, w2c, torch.zeros(1, dtype=torch.long, device=dev), 64, 64)
     assert [tuple(f.shape) for f in feats] == [(1, 64, 16, 8, 8), (1, 128, 16, 4, 4), (1, 128, 16, 2, 2), (1, 128, 16, 1, 1)]
     assert all(torch.isfinite(f).all() for f in feats)
+
+
+def test_conditional_mask_and_conv3d(golden_dir):
+    """Rectangular (target x context) epipolar mask bits vs the reference fixture, and the 3x3x3 latent projection."""
+    from camc2v_amd import camera, ops
+    fx = dict(np.load(os.path.join(golden_dir, "pose_small.npz")))
+    dev = torch.device("cuda:0")
+    F = camera.conditional_fundamental(torch.from_numpy(fx["cond_K"]).to(dev), torch.from_numpy(fx["cond_w2c"]).to(dev),
+                                       torch.from_numpy(fx["cond_w2c_ctx"]).to(dev), torch.from_numpy(fx["cond_index"]).to(dev))
+    l2, mx = _rel(F, fx["cond_F"])
+    assert l2 < 1e-4
+    shape = tuple(int(v) for v in fx["cond_mask_shape"])                       # [1, 256, 192]
+    mp = ops.epipolar_mask_bits(torch.from_numpy(fx["cond_F"]).to(dev), 4, 8, 8, 8)
+    got = np.unpackbits(mp[0].cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[..., :shape[-1]]
+    ref = np.unpackbits(fx["cond_mask"], axis=-1, bitorder="little")[..., :shape[-1]]
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    g = torch.Generator().manual_seed(8)
+    x, w, b = torch.randn(2, 4, 5, 6, 7, generator=g), torch.randn(4, 4, 3, 3, 3, generator=g) * 0.2, torch.randn(4, generator=g)
+    add = torch.randn(2, 4, 6, 7, generator=g)
+    ref = torch.nn.functional.conv3d(x, w, b, padding=1) + add[:, :, None]
+    l2, mx = _rel(ops.conv3d_small(x.to(dev), w.to(dev), b.to(dev), add=add.to(dev)), ref)
+    assert l2 < 1e-6
+
+
+def test_context_concat_vs_oracle():
+    """CamContextI2V.context_concat: adaptor over [conditioning ; context] latents with the conditional epipolar mask,
+    Conv3d latent projection, + conditioning latent -- against the oracle pieces composed the same way."""
+    from camc2v_amd import camera
+    from oracle import adaptor_oracle as ao, geometry_oracle as go, unet_oracle
+    from oracle.golden_inputs import SMALL_CFG
+    from utils.utils import instantiate_from_config
+    acfg = dict(ao.FULL_CFG, query_dim=128, num_queries=64, video_length=4, depth=2)
+    model = instantiate_from_config({"target": "model.camcontexti2v.CamContextI2V", "params": dict(
+        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG},
+        conditioning_key="hybrid", channels=4, image_size=[8, 8], temporal_length=4, scale_factor=0.18215,
+        multi_cond_strategy="token_concat_latent_epipolar", use_zero_conv_latent_input=True,
+        multi_latent_adaptor={"target": "model.modules.adaptors.MultiLatentEpipolarAdaptor", "params": acfg})})
+    assert model.build_feeders() == ["multi_cond_latent_adaptor"]
+    man = {k: list(v.shape) for k, v in model.multi_cond_latent_adaptor.state_dict().items()}
+    sd = unet_oracle.seeded_state_dict(man, 12, std=0.05)
+    model.multi_cond_latent_adaptor.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(13)
+    wproj, bproj = torch.randn(4, 4, 3, 3, 3, generator=g) * 0.1, torch.randn(4, generator=g) * 0.1
+    with torch.no_grad():
+        model.multi_cond_in_projection.weight.copy_(wproj)
+        model.multi_cond_in_projection.bias.copy_(bproj)
+    model = model.cuda()
+    dev = torch.device("cuda:0")
+    T, n = 4, 2
+    K = torch.tensor([[32.0, 0, 32], [0, 32, 32], [0, 0, 1]]).repeat(1, T, 1, 1)
+    w2c = go.synthetic_trajectory(1, T)
+    w2c_ctx = go.synthetic_trajectory(1, 8)[:, [5, 7]]
+    cond_idx = torch.zeros(1, dtype=torch.long)
+    z_cond, z_ctx = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, n, 8, 8, generator=g)
+    with torch.no_grad():
+        F = go.conditional_fundamental(K, w2c, w2c_ctx, cond_idx)
+        mask = go.epipolar_mask(F, 8, 8, 8)
+        tokens = torch.cat([z_cond[:, :, None], z_ctx], 2).permute(0, 2, 3, 4, 1).reshape(1, -1, 4)
+        lat = ao.adaptor_forward(sd, acfg, tokens, mask)
+        x = lat.reshape(1, T, 8, 8, 4).permute(0, 4, 1, 2, 3)
+        ref = torch.nn.functional.conv3d(x, wproj, bproj, padding=1) + z_cond[:, :, None]
+    got = model.context_concat(z_cond.to(dev), z_ctx.to(dev), K.to(dev), w2c.to(dev), w2c_ctx.to(dev), cond_idx.to(dev))
+    assert got.shape == (1, 4, T, 8, 8)
+    l2, mx = _rel(got, ref)
+    print(f"[parity] context_concat vs oracle composition: rel_l2={l2:.3e} max_rel={mx:.3e}")
+    assert l2 < 1.5e-2
