@@ -20,6 +20,6 @@ def test_generate_demo_two_steps():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["frames"] == [1, 3, 16, 256, 256]
-    for key in ("first_stage_encode_3_images_ms", "pose_encoder_ms", "context_adaptor_ms", "resampler_ms", "ddim_2_cfg_steps_ms",
+    for key in ("first_stage_encode_3_images_ms", "pose_encoder_ms", "context_concat_adaptor_ms", "resampler_ms", "ddim_2_cfg_steps_ms",
                 "first_stage_decode_16_frames_ms"):
         assert line[key] > 0

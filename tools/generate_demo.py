@@ -47,6 +47,7 @@ def main():
     model.eval()
     model.model.diffusion_model.prepare()
 
+    torch.linalg.inv(torch.eye(4, device=dev)[None])      # loads the solver library (seconds on a fresh box) outside the stage timers
     g = torch.Generator(device=dev).manual_seed(5)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)
     T, px, n_ctx = 16, 256, 2
@@ -67,11 +68,11 @@ def main():
     cond_idx = torch.zeros(1, dtype=torch.long, device=dev)
     feats = timed("pose_encoder_ms", lambda: model.pose_features(K, w2c, cond_idx, px, px))
     cam = timed("epipolar_masks_ms", lambda: model.camera_condition(K, w2c, cond_idx, px, px, pluker_features=feats, generator=g))
-    # adaptor: latents of the (1 + n_ctx) frames as context tokens; synthetic target-vs-context visibility at 5 %
-    x_tok = z_ctx.permute(0, 2, 3, 1).reshape(1, (1 + n_ctx) * 1024, 4)
-    mask = torch.rand(1, T * 1024, (1 + n_ctx) * 1024, device=dev, generator=g) < 0.05
-    c_lat = timed("context_adaptor_ms", lambda: model.multi_cond_latent_adaptor(x_tok, mask))
-    c_concat = (z_ctx[:1, :, None] + c_lat.reshape(1, T, 32, 32, 4).permute(0, 4, 1, 2, 3)).contiguous()
+    # c_concat: adaptor over the latents of the conditioning + context frames with the target x context epipolar mask,
+    # Conv3d latent projection, + conditioning latent (context poses: two views further along the trajectory)
+    w2c_ctx = camera.synthetic_trajectory(1, 2 * T, dev)[:, [T + 3, 2 * T - 1]]
+    z_cond, z_extra = z_ctx[:1], z_ctx[1:].permute(1, 0, 2, 3)[None]
+    c_concat = timed("context_concat_adaptor_ms", lambda: model.context_concat(z_cond, z_extra, K, w2c, w2c_ctx, cond_idx))
     clip_tokens = rn(1 + n_ctx, 257, 1280)                                              # stand-in for the OpenCLIP image tokens
     img_ctx = timed("resampler_ms", lambda: model.image_proj_model(clip_tokens)).reshape(1, (1 + n_ctx) * 256, 1024)
     text = rn(1, 77, 1024)
