@@ -761,7 +761,10 @@ inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
     // measured on MI355X (tools/famtile_probe.py): the loop hides its DMA latency only with two or more workgroups per
     // CU in flight, so a tile size is taken once it yields >= 1.5 workgroups per CU (256 CUs); e.g. 8192x640x640:
     // 128x128 (320 tiles) 24.4 us, 64x128 (640 tiles) 20.3 us; 2048x1280x1280: 64x128 22.9 us, 64x64 19.3 us
-    const long want = tune_env("CCV_GEMM_WANT") > 0 ? tune_env("CCV_GEMM_WANT") : 384;
+    // long-K problems (>= 48 slabs of 64) keep the larger tile: split-K supplies their workgroups
+    // (2048x1280 with K = 3840 / 5120 in-model: 64x128 + split 2 = 47 / 58 us, 64x64 unsplit = 54 / 67 us)
+    const bool long_k = p.taps * (p.K / BK) >= 48 && !(tune_env("CCV_GEMM_NO5") > 0 && (tune_env("CCV_GEMM_NO5") & 16));
+    const long want = tune_env("CCV_GEMM_WANT") > 0 ? tune_env("CCV_GEMM_WANT") : (long_k ? 256 : 384);
     if (p.N % 128 == 0 && tiles(128, 128) >= want) { mt = 4; nt = 4; return; }
     if (p.N % 128 == 0 && tiles(64, 128) >= want) { mt = 2; nt = 4; return; }
     if (p.N % 64 == 0 && tiles(128, 64) >= (want == 256 ? 320 : want)) { mt = 4; nt = 2; return; }
