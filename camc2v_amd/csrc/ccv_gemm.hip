@@ -763,7 +763,7 @@ inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
     // 128x128 (320 tiles) 24.4 us, 64x128 (640 tiles) 20.3 us; 2048x1280x1280: 64x128 22.9 us, 64x64 19.3 us
     // long-K problems (>= 48 slabs of 64) keep the larger tile: split-K supplies their workgroups
     // (2048x1280 with K = 3840 / 5120 in-model: 64x128 + split 2 = 47 / 58 us, 64x64 unsplit = 54 / 67 us)
-    const bool long_k = p.taps * (p.K / BK) >= 48 && !(tune_env("CCV_GEMM_NO5") > 0 && (tune_env("CCV_GEMM_NO5") & 16));
+    const bool long_k = p.taps * (p.K / BK) >= 48;
     const long want = tune_env("CCV_GEMM_WANT") > 0 ? tune_env("CCV_GEMM_WANT") : (long_k ? 256 : 384);
     if (p.N % 128 == 0 && tiles(128, 128) >= want) { mt = 4; nt = 4; return; }
     if (p.N % 128 == 0 && tiles(64, 128) >= want) { mt = 2; nt = 4; return; }
@@ -895,18 +895,17 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     if (forced_ring == -1 || !ring_on || p.a_f32) return family();
     if (forced_ring >= 0) return ring_fits(p, forced_ring) ? ring(forced_ring, forced_split > 0 ? forced_split : 1) : family();
     const long tiles0 = (long)((p.M + 127) / 128) * (p.N / 320);   // 128x320 tiles (meaningful when N % 320 == 0)
-    const int no5 = tune_env("CCV_GEMM_NO5");                      // tuning aid: 1 = no GEGLU rule, 2 = no conv rule, 3 = neither
     if (p.taps == 1) {
         // GEGLU up-projections (N = 8C): the 128x320 tile at two workgroups per CU once it fills them
-        if (p.geglu && ring_fits(p, 5) && tiles0 >= 512 && !(no5 > 0 && (no5 & 1))) return ring(5, 1);
+        if (p.geglu && ring_fits(p, 5) && tiles0 >= 512) return ring(5, 1);
         return family();
     }
     if (!ring_fits(p, 2)) return family();
     const long tiles2 = (long)((p.M + 127) / 128) * (p.N / 160);   // 128x160 tiles
-    const int r160 = (no5 > 0 && (no5 & 4)) ? 6 : 2;               // tuning aid: 2-stage instead of 4-stage 128x160 tile
+    constexpr int r160 = 2;   // 4-stage 128x160 tile (the 2-stage instance, index 6, measured equal in-model)
     if (p.taps == 3) return tiles2 >= 512 ? ring(r160, 1) : family();
     // long-K 3x3 convolutions: 128x320 tiles, two workgroups per CU, split-K up to ~512 workgroups
-    if (ring_fits(p, 5) && nslab >= 256 && tiles0 >= 64 && !(no5 > 0 && (no5 & 2))) return ring(5, (int)(tiles0 >= 512 ? 1 : 512 / tiles0));
+    if (ring_fits(p, 5) && nslab >= 256 && tiles0 >= 64) return ring(5, (int)(tiles0 >= 512 ? 1 : 512 / tiles0));
     if (tiles2 >= 512) return ring(r160, 1);
     int sp = (int)(256 / tiles2);
     if (sp < 1) sp = 1;
