@@ -2,7 +2,10 @@
 """Condense rocprofv3 CSV output (kernel trace, kernel stats, PMC counter collection) into small text
 summaries that can be committed under profiles/.
 
-    python tools/summarize_rocprof.py <rocprof_out_dir> <summary.txt> [--delete]
+    python tools/summarize_rocprof.py <rocprof_out_dir> <summary.txt> [--delete] [--by-grid KERNEL_SUBSTRING]
+
+--by-grid adds a per-launch-grid breakdown of one kernel (one row per distinct workgroup count), so that a single
+problem shape of a templated kernel (e.g. the QKV projection bench.py times live) can be read out of the trace.
 """
 import collections
 import csv
@@ -24,10 +27,19 @@ def main():
     counters = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
     if traces:
         agg = collections.defaultdict(lambda: [0, 0, 10 ** 18, 0])
+        by_grid = collections.defaultdict(lambda: [0, 0, 10 ** 18, 0])
+        grid_of = sys.argv[sys.argv.index("--by-grid") + 1] if "--by-grid" in sys.argv else None
         t_first, t_last = 10 ** 30, 0
         for r in csv.DictReader(open(traces[0])):
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             a = agg[short(r["Kernel_Name"])]
+            if grid_of and grid_of in short(r["Kernel_Name"]) and "Grid_Size_X" in r:
+                wgs = int(r["Grid_Size_X"]) // max(int(r.get("Workgroup_Size_X", 1) or 1), 1)
+                g = by_grid[(short(r["Kernel_Name"]), wgs)]
+                g[0] += 1
+                g[1] += d
+                g[2] = min(g[2], d)
+                g[3] = max(g[3], d)
             a[0] += 1
             a[1] += d
             a[2] = min(a[2], d)
@@ -39,6 +51,11 @@ def main():
         out.append(f"{'kernel':92s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             out.append(f"{k:92s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.1f} {a[2] / 1e3:9.1f} {a[3] / 1e3:9.1f} {100 * a[1] / tot:6.2f}")
+        if traces and by_grid:
+            out.append(f"# per-grid breakdown of kernels matching {grid_of!r} (workgroups per launch)")
+            out.append(f"{'kernel':60s} {'workgroups':>10s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")
+            for (k, wgs), g in sorted(by_grid.items(), key=lambda kv: -kv[1][1]):
+                out.append(f"{k:60s} {wgs:10d} {g[0]:7d} {g[1] / 1e6:10.3f} {g[1] / g[0] / 1e3:9.1f} {g[2] / 1e3:9.1f} {g[3] / 1e3:9.1f}")
     if counters:
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         calls = collections.defaultdict(int)
