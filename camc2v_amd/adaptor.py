@@ -37,6 +37,52 @@ def _sinusoid(n, dim, device, max_period=10000.0):
     return torch.cat([emb, torch.zeros_like(emb[:, :1])], -1) if dim % 2 else emb
 
 
+class CrossNormalization(nn.Module):
+    """``model.modules.utils.CrossNormalization`` (reference model/modules/utils.py:5-45) on ``ccv_cross_norm``: x is moved to
+    the mean and (unbiased) standard deviation x_ref has over ``dims``.  Built for dims = (-3, -2, -1), the only value the
+    reference constructs (model/camcontexti2v.py:80); the leading dimensions of x_ref must equal those of x or be 1 from
+    some position on (the broadcasts of model/camcontexti2v.py:357-360)."""
+
+    def __init__(self, dims, eps=1e-5):
+        super().__init__()
+        if tuple(dims) != (-3, -2, -1):
+            raise NotImplementedError("CrossNormalization: only dims = (-3, -2, -1) is built")
+        self.dims, self.eps = tuple(dims), eps
+        self._enabled = True
+
+    def enable(self):
+        self._enabled = True
+
+    def disable(self):
+        self._enabled = False
+
+    @torch.no_grad()
+    def forward(self, x, x_ref=None):
+        if not self._enabled:
+            return x
+        if not x.is_cuda:
+            raise CcvError("CrossNormalization.forward: the product path runs on the GPU only (see oracle/adaptor_oracle.py)")
+        x_ref = x if x_ref is None else x_ref
+        if x.dim() < 3 or x_ref.dim() < 3:
+            raise CcvError("CrossNormalization: inputs need at least three dimensions")
+        lead, lead_ref = list(x.shape[:-3]), list(x_ref.shape[:-3])
+        lead_ref = [1] * (len(lead) - len(lead_ref)) + lead_ref
+        if len(lead_ref) != len(lead):
+            raise CcvError(f"CrossNormalization: reference {tuple(x_ref.shape)} has more leading dimensions than x {tuple(x.shape)}")
+        j = 0
+        while j < len(lead) and lead_ref[j] == lead[j]:
+            j += 1
+        if any(d != 1 for d in lead_ref[j:]):
+            raise CcvError(f"CrossNormalization: cannot broadcast reference {tuple(x_ref.shape)} over x {tuple(x.shape)}")
+        n, per_ref = 1, 1
+        for d in lead:
+            n *= d
+        for d in lead[j:]:
+            per_ref *= d
+        # the reference adds the literal 1e-5 to std_x, not self.eps (utils.py:43)
+        return ops.cross_norm(x, x_ref, max(n, 1), per_ref, eps=1e-5).reshape(x.shape)
+
+
 class MultiLatentEpipolarAdaptor(nn.Module, _Prepared):
     def __init__(self, query_dim=512, depth=8, dim_head=64, heads=16, num_queries=1024, output_queries=None,
                  embedding_dim=768, output_dim=1024, ff_mult=4, num_register_tokens=2, use_mask=True, checkpoint=False,
@@ -148,4 +194,4 @@ class MultiLatentEpipolarAdaptor(nn.Module, _Prepared):
         return ops.layernorm_small(y, pk["g_out"], pk["bt_out"], eps=self.norm_out.eps).reshape(B, Lq, self.output_dim)
 
 
-__all__ = ["MultiLatentEpipolarAdaptor", "FeedForward", "EpipolarCrossAttention", "CcvError"]
+__all__ = ["MultiLatentEpipolarAdaptor", "CrossNormalization", "FeedForward", "EpipolarCrossAttention", "CcvError"]

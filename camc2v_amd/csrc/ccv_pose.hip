@@ -66,6 +66,40 @@ __global__ void avgpool2_rows_kernel(const float4* x, float4* y, int n, int H, i
     }
 }
 
+// Cross-normalisation (model/modules/utils.py:30-45): slice s of x (len_x contiguous fp32) is shifted and scaled to the
+// mean / unbiased std of reference slice s / per_ref (len_ref contiguous fp32):
+//   y = (x - mean_x) * (std_ref / (std_x + 1e-5)) + mean_ref.
+// One workgroup per slice; mean first, then the centred sum of squares (both slices are read twice, the second time from
+// cache); reductions run in a fixed order (lane tree, then wave 0..3), so the result is reproducible.
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                      // sh may still be read by the previous call
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void cross_norm_kernel(const float* x, const float* ref, float* y, int64_t len_x, int64_t len_ref,
+                                                         int per_ref, float eps) {
+    __shared__ float sh[4];
+    const float* xs = x + (int64_t)blockIdx.x * len_x;
+    const float* rs = ref + (int64_t)(blockIdx.x / per_ref) * len_ref;
+    float* ys = y + (int64_t)blockIdx.x * len_x;
+    float a = 0.f, b = 0.f;
+    for (int64_t i = threadIdx.x; i < len_x; i += 256) a += xs[i];
+    for (int64_t i = threadIdx.x; i < len_ref; i += 256) b += rs[i];
+    const float mean_x = block_sum256(a, sh) / (float)len_x;
+    const float mean_r = block_sum256(b, sh) / (float)len_ref;
+    a = b = 0.f;
+    for (int64_t i = threadIdx.x; i < len_x; i += 256) { const float d = xs[i] - mean_x; a += d * d; }
+    for (int64_t i = threadIdx.x; i < len_ref; i += 256) { const float d = rs[i] - mean_r; b += d * d; }
+    const float std_x = sqrtf(block_sum256(a, sh) / (float)(len_x - 1));       // torch.std: unbiased
+    const float std_r = sqrtf(block_sum256(b, sh) / (float)(len_ref - 1));
+    const float scale = std_r / (std_x + eps);
+    for (int64_t i = threadIdx.x; i < len_x; i += 256) ys[i] = (xs[i] - mean_x) * scale + mean_r;
+}
+
 // softmax(q k^T scale) v over T <= 16 tokens with head width D <= 256 (multiple of 8): one wave per (batch, head);
 // q / k / v rows staged in LDS, lane (t = lane & 15, g = lane >> 4) scores keys g, g+4, g+8, g+12 for query t, the
 // probabilities go through LDS and the lane then accumulates its quarter of the D output columns.
@@ -214,5 +248,18 @@ extern "C" int ccv_conv3d_small(const float* x, const float* w, const float* bia
     hipLaunchKernelGGL(conv3d_small_kernel, grid1d_pose((int64_t)B * T * H * W), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias, add, y,
                        B, Cin, Cout, T, H, W);
     CCV_LAUNCH_CHECK("ccv_conv3d_small");
+    return CCV_OK;
+}
+
+extern "C" int ccv_cross_norm(const float* x, const float* ref, float* y, int32_t n_slices, int64_t len_x, int32_t slices_per_ref,
+                              int64_t len_ref, float eps, void* stream) {
+    CCV_REQUIRE(x && ref && y && n_slices > 0 && slices_per_ref > 0, CCV_EINVAL, "ccv_cross_norm: bad args");
+    CCV_REQUIRE(len_x > 1 && len_ref > 1, CCV_ESHAPE, "ccv_cross_norm: the unbiased std needs slices of at least 2 elements (got %ld, %ld)",
+                (long)len_x, (long)len_ref);
+    CCV_REQUIRE(n_slices % slices_per_ref == 0, CCV_ESHAPE, "ccv_cross_norm: %d slices do not divide into groups of %d per reference slice",
+                n_slices, slices_per_ref);
+    hipLaunchKernelGGL(cross_norm_kernel, dim3((unsigned)n_slices), dim3(256), 0, static_cast<hipStream_t>(stream), x, ref, y, len_x, len_ref,
+                       slices_per_ref, eps);
+    CCV_LAUNCH_CHECK("ccv_cross_norm");
     return CCV_OK;
 }

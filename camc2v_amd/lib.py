@@ -67,6 +67,7 @@ SIGNATURES = {
     "ccv_ray_condition": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ccv_pixel_unshuffle_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "ccv_conv3d_small": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ccv_cross_norm": (i32, [vp, vp, vp, i32, i64, i32, i64, f32, vp]),
     "ccv_epipolar_mask_bits_rect": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ccv_avgpool2_rows": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ccv_layernorm_small": (i32, [vp, vp, vp, vp, i64, i32, i64, f32, vp]),

@@ -103,17 +103,25 @@ class CamContextI2V(CameraControlLVDM):
     The context-frame adaptor only changes the *inputs* (c_concat, c_crossattn length); the UNet is the
     same as CamI2V's."""
 
-    def __init__(self, *args, multi_cond_strategy=None, use_zero_conv_latent_input=False, **kwargs):
+    def __init__(self, *args, multi_cond_strategy=None, use_zero_conv_latent_input=False, use_cross_normalization=False,
+                 cross_normalization_mode="spatio_temporal", **kwargs):
         for k in ("plucker_proj_trainable", "epipolar_attn_trainable", "pose_guided_cond_trainable",
                   "multi_cond_adaptor_trainable", "first_unet_block_trainable", "first_unet_block_freeze_steps",
-                  "use_cross_normalization", "use_semantic_branch", "epipolar_mask_freeze_steps",
-                  "cross_normalization_mode", "use_pose_embedding_in_latent_adaptor", "inject_trainable_lora_unet",
+                  "use_semantic_branch", "epipolar_mask_freeze_steps",
+                  "use_pose_embedding_in_latent_adaptor", "inject_trainable_lora_unet",
                   "lora_config", "diffusion_model_trainable_param_list", "pose_encoder_trainable",
                   "cond_stage_trainable", "image_proj_model_trainable", "weight_decay"):
             kwargs.pop(k, None)
         super().__init__(*args, **kwargs)
         self.multi_cond_strategy = multi_cond_strategy
         self.use_zero_conv_latent_input = use_zero_conv_latent_input
+        if cross_normalization_mode not in ("token", "spatio_temporal"):
+            raise ValueError(f"cross_normalization_mode {cross_normalization_mode!r}")
+        self.cross_normalization_mode = cross_normalization_mode
+        if multi_cond_strategy is not None:  # reference camcontexti2v.py:77-80
+            from .adaptor import CrossNormalization
+            self.use_cross_normalization = use_cross_normalization
+            self.cond_cross_norm = CrossNormalization((-3, -2, -1))
         if use_zero_conv_latent_input:      # zero-initialised latent projection (reference camcontexti2v.py:81-84)
             self.multi_cond_in_projection = torch.nn.Conv3d(4, 4, kernel_size=3, stride=1, padding=1)
             torch.nn.init.constant_(self.multi_cond_in_projection.weight, 0.0)
@@ -121,8 +129,8 @@ class CamContextI2V(CameraControlLVDM):
 
     @torch.no_grad()
     def context_concat(self, z_cond, z_context, K, w2c, w2c_context, cond_frame_index):
-        """The ``c_concat`` latents of strategy 'token_concat_latent_epipolar' (reference camcontexti2v.py:334-377 with
-        use_zero_conv_latent_input, without cross normalisation): z_cond [b, 4, h, w] latent of the conditioning frame,
+        """The ``c_concat`` latents of strategy 'token_concat_latent_epipolar' (reference camcontexti2v.py:334-377, with the
+        optional cross normalisation and zero-initialised latent projection): z_cond [b, 4, h, w] latent of the conditioning frame,
         z_context [b, 4, n, h, w] latents of the extra context frames, K [b,t,3,3], w2c [b,t,4,4], w2c_context [b,n,4,4].
         Adaptor over [conditioning ; context] tokens with the target x context epipolar mask -> Conv3d(4,4,3) -> +
         conditioning latent on every frame.  Returns fp32 [b, 4, t, h, w]."""
@@ -139,6 +147,13 @@ class CamContextI2V(CameraControlLVDM):
             F = camera.conditional_fundamental(K, w2c, w2c_context, cond_frame_index)
             mask = ops.epipolar_mask_bits(F, t, h, w, 8)
         lat = adaptor(tokens, mask)                                                    # b (t h w) c
+        if getattr(self, "use_cross_normalization", False):
+            # statistics over (c, h, w) of every frame ('spatio_temporal') or over the whole clip ('token') against the
+            # conditioning latent's (camcontexti2v.py:354-364); the sets of elements are the same in token-major order
+            if self.cross_normalization_mode == "spatio_temporal":
+                lat = self.cond_cross_norm(lat.reshape(b, t, h * w, 1, c), z_cond.reshape(b, 1, c, h, w))
+            else:
+                lat = self.cond_cross_norm(lat.reshape(b, 1, t * h * w, c), z_cond)
         x = lat.reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3).contiguous()             # b c t h w
         if not self.use_zero_conv_latent_input:
             return x

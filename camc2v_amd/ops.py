@@ -314,6 +314,19 @@ def conv3d_small(x, weight, bias=None, add=None):
     return y
 
 
+def cross_norm(x, ref, n_slices, slices_per_ref=1, eps=1e-5):
+    """CrossNormalization over contiguous slices (model/modules/utils.py:30-45): x fp32 = n_slices equal slices, slice s is
+    moved to the mean / unbiased std of ref's slice s // slices_per_ref.  Returns a new fp32 tensor shaped like x."""
+    _dev(x, ref)
+    x, ref = x.float().contiguous(), ref.float().contiguous()
+    if n_slices <= 0 or x.numel() % n_slices or n_slices % slices_per_ref or ref.numel() % (n_slices // slices_per_ref):
+        raise CcvError(f"cross_norm: {x.numel()} / {ref.numel()} elements do not split into {n_slices} slices, {slices_per_ref} per reference")
+    y = torch.empty_like(x)
+    check(lib().ccv_cross_norm(_ptr(x), _ptr(ref), _ptr(y), n_slices, x.numel() // n_slices, slices_per_ref,
+                               ref.numel() // (n_slices // slices_per_ref), float(eps), _stream()), "ccv_cross_norm")
+    return y
+
+
 def layernorm_small(x, gamma, beta, *, eps=1e-5):
     """x fp32 [rows, >= C] (first C = gamma.numel() columns used) -> fp32 [rows, C]; for small once-per-clip tensors."""
     _dev(x, gamma, beta)

@@ -218,6 +218,12 @@ int ccv_avgpool2_rows(const float* x, float* y, int32_t n, int32_t H, int32_t W,
  * (nn.Conv3d(4, 4, 3, 1, 1), model/camcontexti2v.py:81-84, 368-373). */
 int ccv_conv3d_small(const float* x, const float* w, const float* bias, const float* add, float* y, int32_t B, int32_t Cin,
                      int32_t Cout, int32_t T, int32_t H, int32_t W, void* stream);
+/* CrossNormalization over the last three dims (model/modules/utils.py:30-45; used after the context-frame adaptor when
+ * use_cross_normalization is set, model/camcontexti2v.py:354-364): x = n_slices contiguous slices of len_x fp32, slice s
+ * takes the mean and unbiased std of reference slice s / slices_per_ref (len_ref fp32 each):
+ * y = (x - mean_x) * (std_ref / (std_x + eps)) + mean_ref (the reference hard-codes eps = 1e-5 here).  y may alias x. */
+int ccv_cross_norm(const float* x, const float* ref, float* y, int32_t n_slices, int64_t len_x, int32_t slices_per_ref,
+                   int64_t len_ref, float eps, void* stream);
 /* Row softmax fp32 [rows, ldx] -> bf16 [rows, ldy] over L columns: the single-head, 512-wide attention of the first-stage
  * decoder (lvdm/modules/networks/ae_modules.py:66-70) runs as GEMM (QK^T, alpha = C^-1/2) -> this -> GEMM (P V). */
 int ccv_softmax_rows(const float* x, uint16_t* y, int32_t rows, int32_t L, int64_t ldx, int64_t ldy, void* stream);

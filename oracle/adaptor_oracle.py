@@ -7,10 +7,12 @@ Reference anchors (relative to /root/reference/CamContextI2V):
   EpipolarCrossAttention.efficient_forward   model/modules/epipolar.py:75-102
   FeedForward (LayerNorm, Linear, GELU, Linear; no biases)   lvdm/modules/encoders/resampler.py:31-38
   timestep_embedding                          lvdm/models/utils_diffusion.py:8-28
+  CrossNormalization.forward                  model/modules/utils.py:30-45 (its two call forms: model/camcontexti2v.py:354-364)
 Configuration covered: the shipped one (configs/models/camcontexti2v_256.yaml:140-151): no Pluecker input, no context
 positional encoding, timestep_embedding_type 'sinusoidal_embedded', no upscaler.
 
-Parity is pinned by tests/golden/adaptor_small.npz (oracle/gen_golden_adaptor.py ran the reference's module).
+Parity is pinned by tests/golden/adaptor_small.npz (oracle/gen_golden_adaptor.py ran the reference's module) and
+tests/golden/crossnorm_small.npz (oracle/gen_golden_crossnorm.py ran the reference's CrossNormalization).
 """
 import torch
 import torch.nn.functional as F
@@ -77,3 +79,25 @@ def adaptor_forward(sd, cfg, x, mask=None):
     latents = latents + t_emb[None, :, None, :].expand(B, T, per_frame, -1).reshape(B, T * per_frame, -1)
     out = _lin(sd, "proj_out", latents)
     return F.layer_norm(out, (out.shape[-1],), sd["norm_out.weight"], sd["norm_out.bias"], 1e-5)
+
+
+def cross_normalization(x, x_ref=None, dims=(-3, -2, -1)):
+    """CrossNormalization.forward (model/modules/utils.py:30-45): x moved to x_ref's mean / unbiased std over ``dims``;
+    the epsilon added to std_x is the literal 1e-5 of the reference."""
+    x_ref = x if x_ref is None else x_ref
+    mean_ref, std_ref = torch.mean(x_ref, dim=dims, keepdim=True), torch.std(x_ref, dim=dims, keepdim=True)
+    mean_x, std_x = torch.mean(x, dim=dims, keepdim=True), torch.std(x, dim=dims, keepdim=True)
+    return (x - mean_x) * (std_ref / (std_x + 1e-5)) + mean_ref
+
+
+def cross_normalize_adaptor_output(lat, z_cond, T, H, W, mode="spatio_temporal"):
+    """The two call forms after the adaptor (model/camcontexti2v.py:354-364): lat [B, (T H W), D], z_cond [B, D, H, W]
+    -> [B, T, D, H, W]."""
+    B, _, D = lat.shape
+    if mode == "spatio_temporal":
+        x = lat.reshape(B, T, H, W, D).permute(0, 1, 4, 2, 3)
+        return cross_normalization(x, z_cond[:, None])
+    x = cross_normalization(lat[:, None], z_cond)
+    if x.dim() == 4:
+        x = x.squeeze(1)
+    return x.reshape(B, T, H, W, D).permute(0, 1, 4, 2, 3)

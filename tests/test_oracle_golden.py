@@ -216,6 +216,23 @@ def test_vae_decode_oracle_vs_reference_fixture(golden_dir):
     _close(vo.posterior_sample(mom, torch.from_numpy(fx["enc_noise"])), fx["enc_sample"])
 
 
+def test_cross_normalization_oracle_vs_reference_fixture(golden_dir):
+    """CrossNormalization restatement against the reference's module run by oracle/gen_golden_crossnorm.py: the two call
+    forms after the adaptor (per-frame and whole-clip statistics) and the self-referenced form."""
+    from oracle import adaptor_oracle as ao
+    fx = dict(np.load(os.path.join(golden_dir, "crossnorm_small.npz")))
+    lat, z_cond = torch.from_numpy(fx["lat"]), torch.from_numpy(fx["z_cond"])
+    B, T, D, H, W = 2, 4, 4, 8, 8
+    x_st = lat.reshape(B, T, H, W, D).permute(0, 1, 4, 2, 3)
+    for got, key in ((ao.cross_normalization(x_st, z_cond[:, None]), "y_st"), (ao.cross_normalization(lat[:, None], z_cond), "y_tok"),
+                     (ao.cross_normalization(x_st), "y_self"),
+                     (ao.cross_normalize_adaptor_output(lat, z_cond, T, H, W, "spatio_temporal"), "y_st")):
+        assert (got - torch.from_numpy(fx[key])).abs().max().item() < 1e-6, key
+    tok = ao.cross_normalize_adaptor_output(lat, z_cond, T, H, W, "token")
+    want = torch.from_numpy(fx["y_tok"]).reshape(B, T, H, W, D).permute(0, 1, 4, 2, 3)
+    assert (tok - want).abs().max().item() < 1e-6
+
+
 def test_adaptor_oracle_vs_reference_fixture(golden_dir):
     """MultiLatentEpipolarAdaptor restatement (oracle/adaptor_oracle.py) against the reference's module run by
     oracle/gen_golden_adaptor.py (masked with a registers-only row, and unmasked)."""

@@ -152,9 +152,11 @@ def test_conditional_mask_and_conv3d(golden_dir):
     assert l2 < 1e-6
 
 
-def test_context_concat_vs_oracle():
+@pytest.mark.parametrize("cross_norm", [None, "spatio_temporal", "token"])
+def test_context_concat_vs_oracle(cross_norm):
     """CamContextI2V.context_concat: adaptor over [conditioning ; context] latents with the conditional epipolar mask,
-    Conv3d latent projection, + conditioning latent -- against the oracle pieces composed the same way."""
+    (optional cross normalisation,) Conv3d latent projection, + conditioning latent -- against the oracle pieces composed
+    the same way."""
     from camc2v_amd import camera
     from oracle import adaptor_oracle as ao, geometry_oracle as go, unet_oracle
     from oracle.golden_inputs import SMALL_CFG
@@ -164,6 +166,7 @@ def test_context_concat_vs_oracle():
         unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG},
         conditioning_key="hybrid", channels=4, image_size=[8, 8], temporal_length=4, scale_factor=0.18215,
         multi_cond_strategy="token_concat_latent_epipolar", use_zero_conv_latent_input=True,
+        use_cross_normalization=cross_norm is not None, cross_normalization_mode=cross_norm or "spatio_temporal",
         multi_latent_adaptor={"target": "model.modules.adaptors.MultiLatentEpipolarAdaptor", "params": acfg})})
     assert model.build_feeders() == ["multi_cond_latent_adaptor"]
     man = {k: list(v.shape) for k, v in model.multi_cond_latent_adaptor.state_dict().items()}
@@ -187,10 +190,13 @@ def test_context_concat_vs_oracle():
         mask = go.epipolar_mask(F, 8, 8, 8)
         tokens = torch.cat([z_cond[:, :, None], z_ctx], 2).permute(0, 2, 3, 4, 1).reshape(1, -1, 4)
         lat = ao.adaptor_forward(sd, acfg, tokens, mask)
-        x = lat.reshape(1, T, 8, 8, 4).permute(0, 4, 1, 2, 3)
+        if cross_norm is None:
+            x = lat.reshape(1, T, 8, 8, 4).permute(0, 4, 1, 2, 3)
+        else:
+            x = ao.cross_normalize_adaptor_output(lat, z_cond, T, 8, 8, cross_norm).permute(0, 2, 1, 3, 4)   # B T D H W -> B D T H W
         ref = torch.nn.functional.conv3d(x, wproj, bproj, padding=1) + z_cond[:, :, None]
     got = model.context_concat(z_cond.to(dev), z_ctx.to(dev), K.to(dev), w2c.to(dev), w2c_ctx.to(dev), cond_idx.to(dev))
     assert got.shape == (1, 4, T, 8, 8)
     l2, mx = _rel(got, ref)
-    print(f"[parity] context_concat vs oracle composition: rel_l2={l2:.3e} max_rel={mx:.3e}")
+    print(f"[parity] context_concat (cross_norm={cross_norm}) vs oracle composition: rel_l2={l2:.3e} max_rel={mx:.3e}")
     assert l2 < 1.5e-2
