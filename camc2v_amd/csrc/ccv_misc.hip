@@ -170,6 +170,17 @@ __global__ void ddim_update_kernel(const float* x, const float* e_c, const float
     }
 }
 
+// Camera guidance (third forward, lvdm/models/samplers/ddim.py:268-280) folded into the unconditional prediction:
+// out = e_uc + coeff * w(t) * (e_c - e_nc), w = 1 ('constant') or cos((1 - t/999) pi/2) ('cosine', per sample).
+__global__ void camera_cfg_fold_kernel(const float* e_uc, const float* e_c, const float* e_nc, const int64_t* t, float coeff,
+                                       float* out, int64_t per_sample, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float w = coeff;
+        if (t) w *= cosf((1.0f - (float)t[i / per_sample] / 999.0f) * 3.14159265358979323846f * 0.5f);
+        out[i] = e_uc[i] + w * (e_c[i] - e_nc[i]);
+    }
+}
+
 // ---- epipolar mask preparation -----------------------------------------------------------
 // bool bytes [B, Lq, Lk] -> words [B, Lq, W]; one thread per word (32 contiguous bytes).
 __device__ __forceinline__ void mark_block(uint32_t* wave_bits, int64_t b, int Lq, int q, int w, int words) {
@@ -389,6 +400,17 @@ extern "C" int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* 
     hipLaunchKernelGGL(ddim_update_kernel, grid1d(n), dim3(256), 0, st, x, e_c, e_uc, noise, x_prev, pred_x0, coef, scale,
                        rescale ? guidance_rescale : 0.f, per_sample, n, ws);
     CCV_LAUNCH_CHECK("ccv_ddim_cfg_step(update)");
+    return CCV_OK;
+}
+
+extern "C" int ccv_camera_cfg_fold(const float* e_uc, const float* e_c, const float* e_nc, const int64_t* t, float coeff, float* out,
+                                   int32_t n_samples, int64_t per_sample, void* stream) {
+    CCV_REQUIRE(e_uc && e_c && e_nc && out, CCV_EINVAL, "ccv_camera_cfg_fold: null pointer");
+    CCV_REQUIRE(n_samples > 0 && per_sample > 0, CCV_EINVAL, "ccv_camera_cfg_fold: bad sizes");
+    const int64_t n = (int64_t)n_samples * per_sample;
+    hipLaunchKernelGGL(camera_cfg_fold_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), e_uc, e_c, e_nc, t, coeff, out,
+                       per_sample, n);
+    CCV_LAUNCH_CHECK("ccv_camera_cfg_fold");
     return CCV_OK;
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "ccv_timestep_embedding": (i32, [vp, vp, i32, i32, vp]),
     "ccv_add_silu_bf16": (i32, [vp, vp, vp, i64, vp]),
     "ccv_ddim_cfg_step": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, i64, vp, vp]),
+    "ccv_camera_cfg_fold": (i32, [vp, vp, vp, vp, f32, vp, i32, i64, vp]),
     "ccv_pack_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ccv_epipolar_mask_bits": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ccv_attn_group_order": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -403,6 +403,22 @@ def ddim_cfg_step(x, e_c, e_uc, noise, coef, scale, guidance_rescale, want_x0=Tr
     return x_prev, x0
 
 
+def camera_cfg_fold(e_uc, e_c, e_nc, coeff, t=None):
+    """e_uc + coeff * w * (e_c - e_nc): the camera-guidance term of the sampler folded into the unconditional prediction
+    (see ccv_camera_cfg_fold).  t: device int64 [n] timesteps => w = cos((1 - t/999) pi/2) ('cosine'); None => w = 1."""
+    _dev(e_uc, e_c, e_nc, t)
+    for v in (e_uc, e_c, e_nc):
+        if v.dtype != F32 or not v.is_contiguous() or v.shape != e_uc.shape:
+            raise CcvError("camera_cfg_fold: three contiguous fp32 tensors of one shape expected")
+    n = e_uc.shape[0]
+    if t is not None and (t.dtype != torch.long or t.numel() != n or not t.is_contiguous()):
+        raise CcvError("camera_cfg_fold: t must be a contiguous int64 tensor with one timestep per sample")
+    out = torch.empty_like(e_uc)
+    check(lib().ccv_camera_cfg_fold(_ptr(e_uc), _ptr(e_c), _ptr(e_nc), _ptr(t), float(coeff), _ptr(out), n, e_uc.numel() // n, _stream()),
+          "ccv_camera_cfg_fold")
+    return out
+
+
 class MaskPack(tuple):
     """(bits, flags) with the per-64-query-group key-block bitmap and the longest-first group schedule riding along as
     ``.wave_bits`` / ``.group_order``; unpacks as a pair so ``bits, flags = pack_mask(...)`` call sites keep working."""

@@ -271,8 +271,6 @@ class DDIMSampler(object):
             raise NotImplementedError("original-step / quantised / corrected / dropout sampling is not on the hot path")
         if getattr(self.model, "parameterization", "eps") != "eps":
             raise NotImplementedError("only the eps parameterisation is used by the shipped configs")
-        if kwargs.get("camera_cfg", 1.0) != 1.0:
-            raise NotImplementedError("camera_cfg != 1.0 (third forward) is off by default and not built yet")
         x = x.float().contiguous()
         e_uc = None
         if unconditional_conditioning is None or unconditional_guidance_scale == 1.0:
@@ -291,6 +289,18 @@ class DDIMSampler(object):
             else:
                 e_c = self.model.apply_model(x, t, c, **kwargs)
                 e_uc = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
+            camera_cfg = kwargs.get("camera_cfg", 1.0)
+            if kwargs.get("enable_camera_condition") and camera_cfg != 1.0:
+                # third forward without the camera (ddim.py:268-280): model_output += (camera_cfg - 1) w (e_c - e_nc); the term
+                # goes into the unconditional prediction, so the fused guidance + rescale + update kernel runs unchanged
+                scheduler = kwargs.get("camera_cfg_scheduler", "constant")
+                if scheduler not in ("constant", "cosine"):
+                    raise NotImplementedError(f"camera_cfg_scheduler {scheduler!r}")
+                c_no_cam = {k: v for k, v in c.items() if k != "camera_condition"}
+                e_nc = self.model.apply_model(x, t, c_no_cam, **kwargs)
+                e_uc = ops.camera_cfg_fold(e_uc.float().contiguous(), e_c.float().contiguous(), e_nc.float().contiguous(),
+                                           (camera_cfg - 1.0) / (1.0 - unconditional_guidance_scale),
+                                           t.contiguous() if scheduler == "cosine" else None)
         if noise is None and coef is None and float(self.ddim_sigmas[index]) != 0.0:
             shape = (1, *x.shape[1:]) if repeat_noise else x.shape
             noise = torch.randn(shape, device=x.device).expand(x.shape).contiguous()

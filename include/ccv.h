@@ -249,6 +249,13 @@ int ccv_ddim_cfg_step(const float* x, const float* e_c, const float* e_uc, const
                       float* x_prev, float* pred_x0, const float* coef,
                       float scale, float guidance_rescale,
                       int32_t n_samples, int64_t per_sample, float* ws, void* stream);
+/* Camera guidance, the optional third forward of the sampler (lvdm/models/samplers/ddim.py:268-280):
+ *   model_output = e_uc + s (e_c - e_uc) + (camera_cfg - 1) w(t) (e_c - e_nc),  e_nc = conditional prediction without camera,
+ * is the plain guidance formula applied to  out = e_uc + coeff * w(t) * (e_c - e_nc)  with coeff = (camera_cfg - 1)/(1 - s);
+ * this call forms `out` (then handed to ccv_ddim_cfg_step as e_uc).  t: DEVICE int64 [n_samples] timesteps for the
+ * 'cosine' scheduler, w = cos((1 - t/999) pi/2); NULL for 'constant' (w = 1).  out may alias e_uc. */
+int ccv_camera_cfg_fold(const float* e_uc, const float* e_c, const float* e_nc, const int64_t* t, float coeff, float* out,
+                        int32_t n_samples, int64_t per_sample, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Epipolar mask preparation (once per clip).

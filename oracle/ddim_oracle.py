@@ -11,6 +11,8 @@ Reference anchors (relative to /root/reference/CamContextI2V):
   DDIMSampler.p_sample_ddim        lvdm/models/samplers/ddim.py:240-346
   DDIMSampler.ddim_sampling        lvdm/models/samplers/ddim.py:133-238
 """
+import math
+
 import numpy as np
 import torch
 
@@ -63,15 +65,30 @@ def rescale_noise_cfg(noise_cfg, noise_text, guidance_rescale):
     return guidance_rescale * rescaled + (1 - guidance_rescale) * noise_cfg
 
 
-def cfg_ddim_update(x, e_c, e_uc, noise, a_t, a_prev, sigma_t, sqrt_1m_at, scale, guidance_rescale):
+def camera_cfg_weight(t, scheduler="constant"):
+    """ddim.py:272-277: weight of the camera-guidance term for timesteps t (long [b]), one per sample.  (The reference
+    reshapes it to [b, 1, 1, 1], which broadcasts against [b, c, t, h, w] latents only for b == 1; per-sample is the
+    reading that agrees with it there.)"""
+    if scheduler == "constant":
+        return 1.0
+    if scheduler == "cosine":
+        return ((1.0 - t / 999) * math.pi / 2).cos().reshape(-1, *([1] * 4))
+    raise NotImplementedError(scheduler)
+
+
+def cfg_ddim_update(x, e_c, e_uc, noise, a_t, a_prev, sigma_t, sqrt_1m_at, scale, guidance_rescale,
+                    e_nc=None, camera_cfg=1.0, camera_weight=1.0):
     """One guidance + DDIM update, ddim.py:267-346 (eps parameterisation, no dynamic rescale).
 
     e_uc None => no guidance (scale 1).  noise: the N(0,1) draw (injected; the
-    reference draws it with noise_like).  Returns (x_prev, pred_x0, e_t)."""
+    reference draws it with noise_like).  e_nc: conditional prediction without the camera (third forward), used when
+    camera_cfg != 1 (ddim.py:268-280).  Returns (x_prev, pred_x0, e_t)."""
     if e_uc is None:
         e = e_c
     else:
         e = e_uc + scale * (e_c - e_uc)
+        if camera_cfg != 1.0:
+            e = e + (camera_cfg - 1.0) * camera_weight * (e_c - e_nc)
         if guidance_rescale > 0.0:
             e = rescale_noise_cfg(e, e_c, guidance_rescale)
     pred_x0 = (x - sqrt_1m_at * e) / a_t.sqrt()
@@ -81,12 +98,13 @@ def cfg_ddim_update(x, e_c, e_uc, noise, a_t, a_prev, sigma_t, sqrt_1m_at, scale
 
 
 def ddim_sample(apply_cond, apply_uncond, x_T, num_steps, eta, scale, guidance_rescale,
-                noises=None, method="uniform_trailing"):
+                noises=None, method="uniform_trailing", apply_nocam=None, camera_cfg=1.0, camera_cfg_scheduler="constant"):
     """ddim.py:133-238 restricted to the generation kwargs of 02_generate_videos.py:318-327.
 
     apply_cond(x, t_long[b]) -> eps ; apply_uncond likewise (None => no CFG).
     noises: list of per-step N(0,1) tensors (index = loop iteration) or None (=> zeros,
-    exact for eta == 0).  Returns (x_0, [x after every step])."""
+    exact for eta == 0).  apply_nocam + camera_cfg != 1: the third forward of camera guidance (ddim.py:268-280).
+    Returns (x_0, [x after every step])."""
     tab = ddim_tables(num_steps, eta, method)
     ts = tab["timesteps"]
     x = x_T
@@ -98,8 +116,11 @@ def ddim_sample(apply_cond, apply_uncond, x_T, num_steps, eta, scale, guidance_r
         e_c = apply_cond(x, t)
         e_uc = apply_uncond(x, t) if (apply_uncond is not None and scale != 1.0) else None
         z = noises[i] if noises is not None else torch.zeros_like(x)
+        cam = e_uc is not None and apply_nocam is not None and camera_cfg != 1.0
         x, _, _ = cfg_ddim_update(x, e_c, e_uc, z, tab["alphas"][index], tab["alphas_prev"][index],
                                   tab["sigmas"][index], tab["sqrt_one_minus_alphas"][index],
-                                  scale, guidance_rescale)
+                                  scale, guidance_rescale, e_nc=apply_nocam(x, t) if cam else None,
+                                  camera_cfg=camera_cfg if cam else 1.0,
+                                  camera_weight=camera_cfg_weight(t, camera_cfg_scheduler) if cam else 1.0)
         trace.append(x)
     return x, trace

@@ -548,3 +548,57 @@ def test_epipolar_mask_bits_vs_oracle(ops, golden_dir):
             assert nflip <= 1e-4 * float(ref.sum()) + 1, f"px={px} d={d}: {nflip} flipped mask bits"
             if nflip == 0:
                 assert torch.equal(flags, refflags)
+
+
+def test_sampler_camera_guidance_vs_reference_fixture(ops, golden_dir):
+    """DDIMSampler.p_sample_ddim with camera_cfg != 1 (third forward without the camera, constant / cosine weight) against
+    the reference sampler's outputs (oracle/gen_golden_camcfg.py); the model is a duck-typed object returning the fixture's
+    predictions, so this pins the branch logic + ccv_camera_cfg_fold + ccv_ddim_cfg_step."""
+    from camc2v_amd.sampler import DDIMSampler, make_beta_schedule
+    fx = np.load(os.path.join(golden_dir, "ddim_camera_cfg.npz"))
+    betas = make_beta_schedule("linear", 1000, 0.00085, 0.012)
+    ac = np.cumprod(1.0 - betas)
+    x, e_c, e_uc, e_nc = (torch.from_numpy(fx[k]).to(dev()) for k in ("x", "e_c", "e_uc", "e_nc"))
+
+    class Duck:
+        num_timesteps = 1000
+        device = dev()
+        parameterization = "eps"
+        betas = torch.tensor(make_beta_schedule("linear", 1000, 0.00085, 0.012), dtype=torch.float32, device=dev())
+        alphas_cumprod = torch.tensor(ac, dtype=torch.float32, device=dev())
+        alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32, device=dev())
+        calls = []
+
+        def apply_model(self, x_, t_, c_, **kw):
+            cam = c_.get("camera_condition")
+            which = "nc" if cam is None else ("uc" if cam.get("is_uc") else "c")
+            self.calls.append(which)
+            return {"c": e_c, "uc": e_uc, "nc": e_nc}[which][:x_.shape[0]]
+
+    duck = Duck()
+    s = DDIMSampler(duck)
+    s.make_schedule(25, "uniform_trailing", 1.0, verbose=False)
+    for scheduler, camera_cfg, index in (("constant", 2.0, 20), ("cosine", 1.5, 20), ("cosine", 3.0, 2)):
+        tag = f"{scheduler}_{camera_cfg:g}_{index}"
+        z, t = torch.from_numpy(fx[f"{tag}_noise"]).to(dev()), torch.from_numpy(fx[f"{tag}_t"]).to(dev())
+        nb = z.shape[0]
+        duck.calls.clear()
+        cond = {"tag": "c", "camera_condition": {"cond_frame_index": torch.zeros(nb, dtype=torch.long)}}
+        x_prev, x0 = s.p_sample_ddim(x[:nb].contiguous(), cond, t, index=index, unconditional_guidance_scale=7.5,
+                                     unconditional_conditioning={"tag": "uc"}, guidance_rescale=0.7, noise=z,
+                                     enable_camera_condition=True, camera_cfg=camera_cfg, camera_cfg_scheduler=scheduler)
+        assert duck.calls == ["c", "uc", "nc"]
+        assert_close(x_prev, torch.from_numpy(fx[f"{tag}_x_prev"]), 2e-5, f"camera guidance {tag}: x_prev")
+        assert_close(x0, torch.from_numpy(fx[f"{tag}_pred_x0"]), 2e-5, f"camera guidance {tag}: pred_x0")
+    # camera_cfg without enable_camera_condition: two forwards, plain guidance
+    duck.calls.clear()
+    t = torch.full((2,), int(s.ddim_timesteps[2]), dtype=torch.long, device=dev())
+    x_prev, _ = s.p_sample_ddim(x, {"tag": "c", "camera_condition": {}}, t, index=2, unconditional_guidance_scale=7.5,
+                                unconditional_conditioning={"tag": "uc", "camera_condition": {"is_uc": True}}, guidance_rescale=0.7,
+                                noise=torch.from_numpy(fx["disabled_noise"]).to(dev()), camera_cfg=3.0)
+    assert duck.calls == ["c", "uc"]
+    assert_close(x_prev, torch.from_numpy(fx["disabled_x_prev"]), 2e-5, "camera_cfg ignored without enable_camera_condition")
+    with pytest.raises(NotImplementedError):
+        s.p_sample_ddim(x, {"tag": "c", "camera_condition": {}}, t, index=2, unconditional_guidance_scale=7.5,
+                        unconditional_conditioning={"tag": "uc"}, enable_camera_condition=True, camera_cfg=2.0,
+                        camera_cfg_scheduler="linear")

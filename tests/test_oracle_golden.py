@@ -146,6 +146,28 @@ def test_cfg_ddim_step(golden_dir):
     _close(x_prev, fx["noguid_x_prev"], 1e-5)
 
 
+def test_cfg_ddim_step_camera_guidance(golden_dir):
+    """Camera guidance (third forward, camera_cfg != 1; constant and cosine weight) against the reference sampler run by
+    oracle/gen_golden_camcfg.py."""
+    fx = np.load(os.path.join(golden_dir, "ddim_camera_cfg.npz"))
+    tab = ddim_oracle.ddim_tables(25, 1.0)
+    x, e_c, e_uc, e_nc = (torch.from_numpy(fx[k]) for k in ("x", "e_c", "e_uc", "e_nc"))
+    for scheduler, camera_cfg, index in (("constant", 2.0, 20), ("cosine", 1.5, 20), ("cosine", 3.0, 2)):
+        tag = f"{scheduler}_{camera_cfg:g}_{index}"
+        z, t = torch.from_numpy(fx[f"{tag}_noise"]), torch.from_numpy(fx[f"{tag}_t"])
+        nb = z.shape[0]
+        x_prev, pred_x0, _ = ddim_oracle.cfg_ddim_update(
+            x[:nb], e_c[:nb], e_uc[:nb], z, tab["alphas"][index], tab["alphas_prev"][index], tab["sigmas"][index],
+            tab["sqrt_one_minus_alphas"][index], 7.5, 0.7, e_nc=e_nc[:nb], camera_cfg=camera_cfg,
+            camera_weight=ddim_oracle.camera_cfg_weight(t, scheduler))
+        _close(x_prev, fx[f"{tag}_x_prev"], 1e-5)
+        _close(pred_x0, fx[f"{tag}_pred_x0"], 1e-5)
+    # without enable_camera_condition the term is off: plain guidance
+    x_prev, _, _ = ddim_oracle.cfg_ddim_update(x, e_c, e_uc, torch.from_numpy(fx["disabled_noise"]), tab["alphas"][2],
+                                               tab["alphas_prev"][2], tab["sigmas"][2], tab["sqrt_one_minus_alphas"][2], 7.5, 0.7)
+    _close(x_prev, fx["disabled_x_prev"], 1e-5)
+
+
 def test_ddim_three_step_trajectory(small):
     fx, sd, inp, cam = small
     cc = torch.from_numpy(fx["traj_c_concat"])

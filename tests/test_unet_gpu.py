@@ -262,7 +262,8 @@ def _oracle_masks(T, px, cond_index=0):
     return masks
 
 
-def _cfg_trajectory_vs_oracle(unet, sd, target, T, steps, scale, eta, tol):
+def _cfg_trajectory_vs_oracle(unet, sd, target, T, steps, scale, eta, tol, camera_cfg=1.0, camera_cfg_scheduler="constant",
+                              use_graph=False):
     """BASELINE.json configs[3]/[4]-style check: a short CFG DDIM trajectory of the camera-conditioned model, both
     contexts per-frame (77 + 16 T tokens), through the reference-shaped wrapper `target`, against the fp32 oracle
     UNet + oracle sampler run here on the CPU with the same weights, inputs and noise draws."""
@@ -278,12 +279,14 @@ def _cfg_trajectory_vs_oracle(unet, sd, target, T, steps, scale, eta, tol):
     cam_cpu = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks,
                    cond_frame_index=torch.zeros(1, dtype=torch.long), add_type="add_to_main_branch")
 
-    def eps(ctx):
+    def eps(ctx, camera=cam_cpu):
         return lambda x, t: unet_oracle.unet_forward(sd, SMALL_CFG, torch.cat([x, inp["c_concat"]], 1), t, ctx, inp["fs"],
-                                                     cam_cpu, origin_h=64)
+                                                     camera, origin_h=64)
 
     with torch.no_grad():
-        ref, _ = ddim_oracle.ddim_sample(eps(inp["ctx_pf"]), eps(ctx_uc), inp["x_T"], steps, eta, scale, 0.7, noises)
+        ref, _ = ddim_oracle.ddim_sample(eps(inp["ctx_pf"]), eps(ctx_uc), inp["x_T"], steps, eta, scale, 0.7, noises,
+                                         apply_nocam=eps(inp["ctx_pf"], None), camera_cfg=camera_cfg,
+                                         camera_cfg_scheduler=camera_cfg_scheduler)
     core = instantiate_from_config({"target": target, "params": dict(
         unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG},
         linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4, image_size=[8, 8],
@@ -298,8 +301,10 @@ def _cfg_trajectory_vs_oracle(unet, sd, target, T, steps, scale, eta, tol):
     uncond = dict(c_concat=[cc], c_crossattn=[to(ctx_uc)])
     samples, _ = core.sample_log(cond, 1, True, steps, eta=eta, x_T=inp["x_T"], unconditional_guidance_scale=scale,
                                  unconditional_conditioning=uncond, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
-                                 fs=to(inp["fs"]), enable_camera_condition=True, injected_noise=noises)
-    _check(samples, ref.numpy(), f"{target} T={T} CFG {scale}: {steps}-step trajectory vs oracle", *tol)
+                                 fs=to(inp["fs"]), enable_camera_condition=True, injected_noise=noises, use_graph=use_graph,
+                                 **({} if camera_cfg == 1.0 else dict(camera_cfg=camera_cfg, camera_cfg_scheduler=camera_cfg_scheduler)))
+    _check(samples, ref.numpy(), f"{target} T={T} CFG {scale} camera_cfg {camera_cfg}: {steps}-step trajectory vs oracle", *tol)
+    return samples
 
 
 def test_cami2v_baseline_config_trajectory(small):
@@ -313,3 +318,13 @@ def test_32_frame_clip_cfg_3p5(small):
     tokens, context rule 77 + 16*32) at CFG 3.5 against the oracle."""
     unet, _, sd, _, _, _, _ = small
     _cfg_trajectory_vs_oracle(unet, sd, "model.camcontexti2v.CamContextI2V", T=32, steps=2, scale=3.5, eta=0.0, tol=(1e-1, 2e-1))
+
+
+def test_camera_guidance_trajectory(small):
+    """camera_cfg != 1: every step runs a third UNet forward without the camera (lvdm/models/samplers/ddim.py:268-280);
+    cosine weight; eager and hipGraph replay agree bit for bit and match the oracle sampler."""
+    unet, _, sd, _, _, _, _ = small
+    kw = dict(T=16, steps=2, scale=7.5, eta=1.0, tol=(1e-1, 2e-1), camera_cfg=2.0, camera_cfg_scheduler="cosine")
+    eager = _cfg_trajectory_vs_oracle(unet, sd, "model.camcontexti2v.CamContextI2V", **kw)
+    graphed = _cfg_trajectory_vs_oracle(unet, sd, "model.camcontexti2v.CamContextI2V", use_graph=True, **kw)
+    assert torch.equal(eager, graphed)
