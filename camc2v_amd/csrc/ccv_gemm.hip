@@ -751,10 +751,10 @@ int launch(const CcvGemm& p, hipStream_t st) {
 // Tile shape for a problem: the largest tile that still yields >= ~1 workgroup per CU (256 CUs).
 inline int tune_env(const char* name);
 inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
-    const int forced = tune_env("CCV_GEMM_FAMTILE");   // tuning aid: 44 / 24 / 42 / 22
-    if (forced == 44 || forced == 24 || forced == 42 || forced == 22) {
+    const int forced = tune_env("CCV_GEMM_FAMTILE");   // tuning aid: 44 / 24 / 42 / 22 / 45 / 25
+    if (forced == 44 || forced == 24 || forced == 42 || forced == 22 || forced == 45 || forced == 25) {
         mt = forced / 10; nt = forced % 10;
-        if ((nt == 4 && p.N % 128 != 0) || (nt == 2 && p.N % 64 != 0)) { mt = 2; nt = 2; }
+        if ((nt == 4 && p.N % 128 != 0) || (nt == 2 && p.N % 64 != 0) || (nt == 5 && (p.N % 160 != 0 || p.geglu || p.a_f32))) { mt = 2; nt = 2; }
         return;
     }
     auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
@@ -849,9 +849,11 @@ const RingCfg kRing[N_RING] = {
 };
 
 struct Plan {
-    int ring;    // index into kRing, or -1: 128x128-family kernels (gemm_dma_kernel / gemm_kernel)
+    int ring;    // index into kRing, -1: 128x128-family kernels (gemm_dma_kernel / gemm_kernel) with the tile choose_tile
+                 // picks, FAM_128x160 / FAM_64x160: the family kernel on a 160-column tile
     int split;   // split-K factor (1 = none)
 };
+constexpr int FAM_128x160 = -2, FAM_64x160 = -3;   // (64x160: reachable through CCV_GEMM_FAMTILE=25 only)
 
 inline int tune_env(const char* name) {  // CCV_GEMM_TUNE=1 re-reads the tuning variables on every call (probe tools)
     static const bool live = [] { const char* e = getenv("CCV_GEMM_TUNE"); return e && e[0] == '1'; }();
@@ -895,11 +897,28 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     if (forced_ring == -1 || !ring_on || p.a_f32) return family();
     if (forced_ring >= 0) return ring_fits(p, forced_ring) ? ring(forced_ring, forced_split > 0 ? forced_split : 1) : family();
     const long tiles0 = (long)((p.M + 127) / 128) * (p.N / 320);   // 128x320 tiles (meaningful when N % 320 == 0)
-    if (p.taps == 1) {
-        // GEGLU up-projections (N = 8C): the 128x320 tile at two workgroups per CU once it fills them
-        if (p.geglu && ring_fits(p, 5) && tiles0 >= 512) return ring(5, 1);
-        return family();
+    // GEGLU up-projections (N = 8C): the 128x320 tile at two workgroups per CU once it fills them
+    if (p.taps == 1 && p.geglu && ring_fits(p, 5) && tiles0 >= 512) return ring(5, 1);
+    // 160-column family tiles (2 stages of 64-deep slabs = whole 128-byte rows per DMA piece, 72 KiB of LDS, two workgroups
+    // per CU): fewer operand bytes per flop than 128x64 / 64x64 and faster delivery than the ring tiles' 64-byte rows
+    // (tools/probes/l2_lds_probe.hip: 19-25 TB/s against 14-16 TB/s into LDS).  The kernel-level sweep (tools/ring_probe.py)
+    // favours them on most 32x32- and 16x16-latent shapes, but IN THE MODEL (kernel-time totals of rocprofv3 traces of
+    // bench.py, same box, tools/ab_f160.sh) only two rules pay: the 3x3 / temporal convolutions at 32x32 latents (-0.5 %
+    // of all kernel time) and the long-K layers at 8x8 latents with split-K 4 (-0.7 %); on the 32x32-latent linear
+    // layers the GEMMs gain nothing and the kernels that consume their outputs get slower (+17 ms per 77 steps).
+    static const bool f160_on = [] { const char* e = getenv("CCV_GEMM_F160"); return !(e && e[0] == '0'); }();   // A/B aid
+    if (f160_on && forced_ring == -2 /* none forced */ && !p.geglu && p.N % 160 == 0 && p.K % BK == 0) {
+        const long tiles_a = (long)((p.M + 127) / 128) * (p.N / 160);
+        const long kk = (long)p.taps * p.K;
+        auto fam160 = [&](int code, int sp) {
+            const int cap = (int)(kk / BK / 2);
+            if (!allow_split || sp > cap) sp = !allow_split ? 1 : (cap < 1 ? 1 : cap);
+            return Plan{code, sp < 1 ? 1 : sp};
+        };
+        if (p.taps > 1 && tiles_a >= 512 && p.N <= 960) return fam160(FAM_128x160, 1);          // convolutions, 32x32 latents
+        if (tiles_a >= 128 && tiles_a < 256 && kk >= 5120) return fam160(FAM_128x160, 4);       // 8x8 latents, long K
     }
+    if (p.taps == 1) return family();
     if (!ring_fits(p, 2)) return family();
     const long tiles2 = (long)((p.M + 127) / 128) * (p.N / 160);   // 128x160 tiles
     constexpr int r160 = 2;   // 4-stage 128x160 tile (the 2-stage instance, index 6, measured equal in-model)
@@ -942,7 +961,11 @@ int dispatch_tile(const CcvGemm& p, int ring, hipStream_t st) {
     int mt, nt;
     choose_tile(p, mt, nt);
     if (!A_F32 && ring >= 0) return dispatch_ring<GATHER>(p, ring, st);
+    if (!A_F32 && ring == FAM_128x160) return launch_dma<4, 5, GATHER>(p, st);
+    if (!A_F32 && ring == FAM_64x160) return launch_dma<2, 5, GATHER>(p, st);
     if (!A_F32 && dma_enabled()) {
+        if (mt == 4 && nt == 5) return launch_dma<4, 5, GATHER>(p, st);
+        if (mt == 2 && nt == 5) return launch_dma<2, 5, GATHER>(p, st);
         if (mt == 4 && nt == 4) return launch_dma<4, 4, GATHER>(p, st);
         if (mt == 2 && nt == 4) return launch_dma<2, 4, GATHER>(p, st);
         if (mt == 4 && nt == 2) return launch_dma<4, 2, GATHER>(p, st);

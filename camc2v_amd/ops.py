@@ -87,11 +87,36 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     if out.dtype != (F32 if out_f32 else BF16):
         raise CcvError("gemm: out dtype mismatch")
     p.gather = gather
+    # the kernels trust M and the gather geometry: check them against the tensors here, on the host
+    if out.dim() != 2 or out.shape[0] < M or out.shape[1] < n_cols or out.stride(1) != 1:
+        raise CcvError(f"gemm: out {tuple(out.shape)} cannot hold [{M}, {n_cols}]")
+    if residual is not None and (residual.dim() != 2 or residual.shape[0] < M or residual.shape[1] < n_cols):
+        raise CcvError(f"gemm: residual {tuple(residual.shape)} is smaller than the output [{M}, {n_cols}]")
+    if a.shape[1] < K:
+        raise CcvError(f"gemm: A has {a.shape[1]} columns, K = {K}")
     if gather == GATHER_CONV3X3:
         p.out_h, p.out_w, p.src_h, p.src_w, p.stride, p.upsample = conv[:6]
         p.no_lead_pad = int(conv[6]) if len(conv) > 6 else 0
-    elif gather == GATHER_TCONV3:
-        p.frames, p.hw = tconv
+        pix = p.out_h * p.out_w
+        if pix <= 0 or M % pix or a.shape[0] < (M // pix) * p.src_h * p.src_w:
+            raise CcvError(f"gemm: conv3x3 output rows M={M} = images x {p.out_h}x{p.out_w} need {(M // max(pix, 1)) * p.src_h * p.src_w} "
+                           f"source rows ({p.src_h}x{p.src_w} per image), A has {a.shape[0]} (pass m= for strided / upsampling convolutions)")
+    else:
+        if a.shape[0] < M:
+            raise CcvError(f"gemm: A has {a.shape[0]} rows, M = {M}")
+        if gather == GATHER_TCONV3:
+            p.frames, p.hw = tconv
+            if p.frames <= 0 or p.hw <= 0 or M % (p.frames * p.hw):
+                raise CcvError(f"gemm: tconv rows M={M} are not whole clips of {p.frames} frames x {p.hw} pixels")
+    if bias2 is not None:   # [batches, >= N] fp32 rows ldb2 apart (a column slice of a wider table is fine)
+        nb2 = (M + max(rows_per_batch, 1) - 1) // max(rows_per_batch, 1)
+        ok = rows_per_batch > 0 and bias2.dtype == F32
+        if ok and bias2.dim() == 2:
+            ok = bias2.shape[0] >= nb2 and bias2.shape[1] >= N and bias2.stride(1) == 1 and (nb2 == 1 or bias2.stride(0) == ldb2)
+        elif ok:
+            ok = bias2.is_contiguous() and bias2.numel() >= (nb2 - 1) * ldb2 + N
+        if not ok:
+            raise CcvError(f"gemm: bias2 must hold {nb2} fp32 rows of >= {N} columns, ldb2 = {ldb2} apart")
     p.rows_per_batch = rows_per_batch
     p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), int(out_f32), alpha
     ws_bytes = lib().ccv_gemm_ws_bytes(C.byref(p))

@@ -102,7 +102,8 @@ int ccv_gemm(const CcvGemm* p, void* stream);
 /* Which kernel ccv_gemm would run for this problem when the workspace is provided (introspection for tests and
  * the tuning tools; no device work): *tile = index of the LDS-ring tile configuration (0: 128x320, 1: 64x320,
  * 2: 128x160, 3: 64x160 4-deep, 4: 64x160 8-deep, 5: 128x320 2-deep at two workgroups per CU, 6: 128x160 2-deep, 7: 64x320 2-deep; the last two are tuning
- * candidates the planner does not pick) or -1 for the 128x128-family kernels; *split = split-K factor. */
+ * candidates the planner does not pick), -1 for the 128x128-family kernels (two stages of 64-deep slabs) on the tile they
+ * choose by workgroup count, -2 for that kernel on a 128x160 tile; *split = split-K factor. */
 int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
 
 /* ------------------------------------------------------------------------------------

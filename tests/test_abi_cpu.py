@@ -84,14 +84,15 @@ def test_gemm_planner_host_logic(built):
     assert _plan(built, 32768, 960, 320) == (-1, 1)                      # QKV projection: 128x128 family, unsplit
     assert _plan(built, 32768, 2560, 320, geglu=1) == (5, 1)             # GEGLU up-projection: 2-stage 128x320 tile
     assert _plan(built, 512, 10240, 1280, geglu=1) == (-1, 1)            # ... unless its 128 tiles would leave CUs idle
-    assert _plan(built, 2048, 1280, 5120) == (-1, 2)                     # FF down-projection at 8x8 latents: long K -> 64x128 tiles, split 2
+    assert _plan(built, 2048, 1280, 5120) == (-2, 4)                     # FF down-projection at 8x8 latents: long K -> 128x160 family tile, split 4
     assert _plan(built, 512, 1280, 5120) == (-1, 4)                      # ... at 4x4 latents: 160 tiles, split-K 4
-    assert _plan(built, 32768, 320, 320, taps=9, gather=1) == (2, 1)     # conv3x3 at 32x32 latents: 128x160 ring tile
-    assert _plan(built, 32768, 320, 960, taps=9, gather=1) == (5, 2)     # long K: 128x320 tiles, 2 per CU, split to 512
+    assert _plan(built, 32768, 320, 320, taps=9, gather=1) == (-2, 1)    # conv3x3 at 32x32 latents: 128x160 family tile (128-byte rows)
+    assert _plan(built, 32768, 320, 960, taps=9, gather=1) == (-2, 1)
+    assert _plan(built, 8192, 640, 1280, taps=9, gather=1) == (5, 4)     # 16x16 latents, long K: 128x320 tiles, 2 per CU, split to 512
     assert _plan(built, 8192, 640, 640, taps=9, gather=1) == (2, 2)
-    assert _plan(built, 2048, 1280, 2560, taps=9, gather=1) == (5, 8)
+    assert _plan(built, 2048, 1280, 2560, taps=9, gather=1) == (-2, 4)   # 8x8 latents: 128 tiles of 128x160 x split 4
     assert _plan(built, 512, 1280, 1280, taps=9, gather=1) == (2, 8)     # 4x4 latents: 32 tiles x 8 splits
-    assert _plan(built, 32768, 320, 320, taps=3, gather=2) == (2, 1)
+    assert _plan(built, 32768, 320, 320, taps=3, gather=2) == (-2, 1)
     assert _plan(built, 2048, 1280, 1280, taps=3, gather=2) == (-1, 2)
     assert _plan(built, 512, 1280, 1280, taps=3, gather=2) == (-1, 3)
     assert _plan(built, 32768, 512, 2048) == (-1, 1)                     # N not a multiple of 160: never a ring tile

@@ -237,6 +237,46 @@ def test_gemm_ring_configs(ops, ring, split, monkeypatch):
     assert_close(out.reshape(b, t, hw, 320).permute(0, 3, 1, 2), F.conv3d(xt, wtt, None, padding=(1, 0, 0))[..., 0], 2e-3, "ring tconv3")
 
 
+@pytest.mark.parametrize("tile,split", [(45, 1), (45, 4), (25, 1), (25, 2)])
+def test_gemm_family_160_column_tiles(ops, tile, split, monkeypatch):
+    """The family kernel (two stages of 64-deep slabs) on its 128x160 / 64x160 tiles, forced through the tuning variables,
+    unsplit and split-K: ragged-M linear with residual, conv3x3 with padding (stride 1 and 2), temporal conv; each against
+    the fp32 torch reference of the same op.  (The planner picks the 128x160 tile for the 32x32-latent convolutions and the
+    long-K layers at 8x8 latents.)"""
+    from camc2v_amd.pack import pack_conv3x3, pack_tconv3
+    monkeypatch.setenv("CCV_GEMM_RING", "-1")
+    monkeypatch.setenv("CCV_GEMM_FAMTILE", str(tile))
+    monkeypatch.setenv("CCV_GEMM_SPLIT", str(split))
+    monkeypatch.setattr(ops, "TRACK_GEMM_PLAN", True)
+    M, N, K = 1024 + 40, 640, 2048
+    a, w = rnd(M, K, seed=280), rnd(N, K, seed=281, scale=0.02)
+    bias, res = rnd(N, seed=282, dtype=torch.float32), rnd(M, N, seed=283, dtype=torch.float32)
+    ref = a.float() @ w.float().t() + bias
+    assert_close(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref + res, 2e-3, "160-column linear + residual")
+    assert ops.LAST_GEMM_PLAN == (-1, split)
+    assert_close(ops.gemm(a, w, bias=bias, act=ops.ACT_SILU), F.silu(ref), 1e-2, "160-column linear + SiLU, bf16 out")
+    n, cin, cout, hs = 6, 256, 320, 12
+    x = rnd(n, cin, hs, hs, seed=287, dtype=torch.float32).to(torch.bfloat16).float()
+    wt = rnd(cout, cin, 3, 3, seed=288, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    cb = rnd(cout, seed=289, dtype=torch.float32)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, bias=cb, gather=ops.GATHER_CONV3X3, conv=(hs, hs, hs, hs, 1, 0), out_f32=True)
+    assert_close(out.reshape(n, hs, hs, cout).permute(0, 3, 1, 2), F.conv2d(x, wt, cb, padding=1), 2e-3, "160-column conv3x3")
+    out = ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, m=n * (hs // 2) ** 2, bias=cb, gather=ops.GATHER_CONV3X3,
+                   conv=(hs // 2, hs // 2, hs, hs, 2, 0), out_f32=True)
+    assert_close(out.reshape(n, hs // 2, hs // 2, cout).permute(0, 3, 1, 2), F.conv2d(x, wt, cb, padding=1, stride=2), 2e-3,
+                 "160-column conv3x3 stride 2")
+    from camc2v_amd.lib import CcvError
+    with pytest.raises(CcvError):   # M taken from the source rows: the wrapper refuses instead of letting the gather run past A
+        ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, bias=cb, gather=ops.GATHER_CONV3X3, conv=(hs // 2, hs // 2, hs, hs, 2, 0), out_f32=True)
+    b, c, t, hw = 2, 512, 8, 36
+    xt = rnd(b, c, t, hw, 1, seed=291, dtype=torch.float32).to(torch.bfloat16).float()
+    wtt = rnd(320, c, 3, 1, 1, seed=292, scale=0.05, dtype=torch.float32).to(torch.bfloat16).float()
+    rows = xt[..., 0].permute(0, 2, 3, 1).reshape(-1, c).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_tconv3(wtt), k=c, taps=3, gather=ops.GATHER_TCONV3, tconv=(t, hw), out_f32=True)
+    assert_close(out.reshape(b, t, hw, 320).permute(0, 3, 1, 2), F.conv3d(xt, wtt, None, padding=(1, 0, 0))[..., 0], 2e-3, "160-column tconv3")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from camc2v_amd.lib import CcvError
     with pytest.raises(CcvError):
