@@ -275,70 +275,85 @@ inline int gn_small_gpb(int instances, int rows_per_instance, int C, bool x_f32)
 // columns per lane the instance is compiled for (C <= 4 * LPR * LN_MAX4).  The layers here have C = 320 / 640 /
 // 1280 at 32768 / 8192 / 2048 rows: LPR = C/20 keeps 5 float4 (20 registers) per lane at every width, 8 waves per
 // SIMD resident, and the narrow-and-long as well as the wide-and-short activations spread over all CUs.
-template <int LPR, int LN_MAX4>
+template <int LPR, int LN_MAX4, int NR>
 __global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, const float* gamma, const float* beta,
                                                  int rows, int C, float eps, const uint16_t* addend, int addend_rows, uint16_t* y2) {
-    constexpr int RPB = 256 / LPR;           // rows per block
-    const int row = blockIdx.x * RPB + (threadIdx.x / LPR);
+    // NR rows per lane group: all their loads are in flight together and gamma / beta are fetched once for them
+    constexpr int RPB = 256 / LPR * NR;      // rows per block
+    const int row0 = blockIdx.x * RPB + (threadIdx.x / LPR) * NR;
     const int l = threadIdx.x % LPR;
     const int cols = C >> 2;                 // float4 columns per row
-    const bool live = row < rows;
-    const float4* xr = reinterpret_cast<const float4*>(x) + (long)(live ? row : 0) * cols;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
-    float4 v[LN_MAX4], gm[LN_MAX4], bt[LN_MAX4];
+    float4 v[NR][LN_MAX4], gm[LN_MAX4], bt[LN_MAX4];
 #pragma unroll
-    for (int i = 0; i < LN_MAX4; ++i) {    // every load of the kernel is issued here, before the first reduction
-        const int c = l + LPR * i;
-        const bool in = c < cols;
-        v[i] = in ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        gm[i] = in ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        bt[i] = in ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float s = 0.f;
+    for (int r = 0; r < NR; ++r) {           // every load of the kernel is issued here, before the first reduction
+        const float4* xr = reinterpret_cast<const float4*>(x) + (long)(row0 + r < rows ? row0 + r : 0) * cols;
 #pragma unroll
-    for (int i = 0; i < LN_MAX4; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX4; ++i) {
-        const int c = l + LPR * i;
-        if (c < cols) {
-            const float a = v[i].x - mean, b = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
-            q += (a * a + b * b) + (d * d + e * e);
+        for (int i = 0; i < LN_MAX4; ++i) {
+            const int c = l + LPR * i;
+            v[r][i] = c < cols ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = rsqrtf(q / (float)C + eps);
-    if (!live) return;
-    uint2* yo = reinterpret_cast<uint2*>(y) + (long)row * cols;
-    uint2* y2o = y2 ? reinterpret_cast<uint2*>(y2) + (long)row * cols : nullptr;
-    const uint2* ad = addend ? reinterpret_cast<const uint2*>(addend) + (long)(row % addend_rows) * cols : nullptr;
-#pragma unroll
     for (int i = 0; i < LN_MAX4; ++i) {
         const int c = l + LPR * i;
-        if (c < cols) {
-            const float4 g = gm[i], bb = bt[i];
-            const float o0 = (v[i].x - mean) * rstd * g.x + bb.x, o1 = (v[i].y - mean) * rstd * g.y + bb.y;
-            const float o2 = (v[i].z - mean) * rstd * g.z + bb.z, o3 = (v[i].w - mean) * rstd * g.w + bb.w;
-            yo[c] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
-            if (y2o) {
-                const uint2 a = ad[c];
-                y2o[c] = make_uint2(pack_bf16x2(o0 + bf16_to_f32((uint16_t)(a.x & 0xffffu)), o1 + bf16_to_f32((uint16_t)(a.x >> 16))),
-                                    pack_bf16x2(o2 + bf16_to_f32((uint16_t)(a.y & 0xffffu)), o3 + bf16_to_f32((uint16_t)(a.y >> 16))));
+        const bool in = c < cols;
+        gm[i] = in ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[i] = in ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mean[NR], rstd[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX4; ++i) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+        mean[r] = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX4; ++i) {
+            const int c = l + LPR * i;
+            if (c < cols) {
+                const float a = v[r][i].x - mean[r], b = v[r][i].y - mean[r], d = v[r][i].z - mean[r], e = v[r][i].w - mean[r];
+                q += (a * a + b * b) + (d * d + e * e);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
+        rstd[r] = rsqrtf(q / (float)C + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        uint2* yo = reinterpret_cast<uint2*>(y) + (long)row * cols;
+        uint2* y2o = y2 ? reinterpret_cast<uint2*>(y2) + (long)row * cols : nullptr;
+        const uint2* ad = addend ? reinterpret_cast<const uint2*>(addend) + (long)(row % addend_rows) * cols : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAX4; ++i) {
+            const int c = l + LPR * i;
+            if (c < cols) {
+                const float4 g = gm[i], bb = bt[i];
+                const float o0 = (v[r][i].x - mean[r]) * rstd[r] * g.x + bb.x, o1 = (v[r][i].y - mean[r]) * rstd[r] * g.y + bb.y;
+                const float o2 = (v[r][i].z - mean[r]) * rstd[r] * g.z + bb.z, o3 = (v[r][i].w - mean[r]) * rstd[r] * g.w + bb.w;
+                yo[c] = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                if (y2o) {
+                    const uint2 a = ad[c];
+                    y2o[c] = make_uint2(pack_bf16x2(o0 + bf16_to_f32((uint16_t)(a.x & 0xffffu)), o1 + bf16_to_f32((uint16_t)(a.x >> 16))),
+                                        pack_bf16x2(o2 + bf16_to_f32((uint16_t)(a.y & 0xffffu)), o3 + bf16_to_f32((uint16_t)(a.y >> 16))));
+                }
             }
         }
     }
 }
 
-template <int LPR, int LN_MAX4>
+template <int LPR, int LN_MAX4, int NR>
 void launch_ln(hipStream_t st, const float* x, uint16_t* y, const float* gamma, const float* beta, int rows, int C, float eps,
                const uint16_t* addend, int ar, uint16_t* y2) {
-    constexpr int RPB = 256 / LPR;
-    hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+    constexpr int RPB = 256 / LPR * NR;
+    hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4, NR>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
 }
 
 // fp32 -> fp32 LayerNorm for the small once-per-clip tensors (the adaptor's 4-channel output norm, the Resampler's
@@ -412,14 +427,17 @@ extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, co
     CCV_REQUIRE(!addend || addend_rows > 0, CCV_EINVAL, "ccv_layernorm: addend_rows must be positive");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ar = addend_rows > 0 ? addend_rows : 1;
+    // two rows per lane group once that still leaves >= 4 workgroups per CU (A/B aid: CCV_LN_ROWS=1)
+    static const int nr_env = [] { const char* e = getenv("CCV_LN_ROWS"); return e ? atoi(e) : 2; }();
+    const bool two = nr_env == 2 && (long)rows * (C <= 320 ? 16 : C <= 640 ? 32 : 64) >= 2l * 256 * 1024;
     if (C <= 320)
-        launch_ln<16, 5>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        two ? launch_ln<16, 5, 2>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2) : launch_ln<16, 5, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else if (C <= 640)
-        launch_ln<32, 5>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        two ? launch_ln<32, 5, 2>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2) : launch_ln<32, 5, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else if (C <= 1280)
-        launch_ln<64, 5>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<64, 5, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else
-        launch_ln<64, 8>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<64, 8, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
     CCV_LAUNCH_CHECK("ccv_layernorm");
     return CCV_OK;
 }
