@@ -290,7 +290,7 @@ class DDIMSampler(object):
                 e_c = self.model.apply_model(x, t, c, **kwargs)
                 e_uc = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
             camera_cfg = kwargs.get("camera_cfg", 1.0)
-            if kwargs.get("enable_camera_condition") and camera_cfg != 1.0:
+            if kwargs.get("enable_camera_condition") and camera_cfg != 1.0 and isinstance(c, dict):
                 # third forward without the camera (ddim.py:268-280): model_output += (camera_cfg - 1) w (e_c - e_nc); the term
                 # goes into the unconditional prediction, so the fused guidance + rescale + update kernel runs unchanged
                 scheduler = kwargs.get("camera_cfg_scheduler", "constant")
