@@ -51,6 +51,27 @@ def main():
         out.append(f"{'kernel':92s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             out.append(f"{k:92s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.1f} {a[2] / 1e3:9.1f} {a[3] / 1e3:9.1f} {100 * a[1] / tot:6.2f}")
+        if "--gaps" in sys.argv:   # idle time between kernels inside the busiest stretch of the trace (the timed loop)
+            iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(traces[0])))
+            segs, cur = [], [iv[0]]
+            for x in iv[1:]:             # stretches separated by more than 2 ms of idle device
+                if x[0] - max(e for _, e in cur[-8:]) > 2_000_000:
+                    segs.append(cur)
+                    cur = []
+                cur.append(x)
+            segs.append(cur)
+            iv = max(segs, key=len)
+            busy_end, idle, hist, launches = iv[0][1], 0, collections.Counter(), len(iv)
+            for a, b in iv[1:]:
+                if a > busy_end:
+                    g = a - busy_end
+                    idle += g
+                    hist["<2us" if g < 2000 else "2-5us" if g < 5000 else "5-20us" if g < 20000 else "20-100us" if g < 100000 else ">=100us"] += g
+                busy_end = max(busy_end, b)
+            span = busy_end - iv[0][0]
+            out.append(f"# gaps inside the busiest stretch: {launches} dispatches, span {span / 1e6:.2f} ms, idle {idle / 1e6:.2f} ms "
+                       f"({100 * idle / span:.1f} %), {idle / max(launches - 1, 1) / 1e3:.2f} us per dispatch")
+            out.append("# idle time by gap size: " + ", ".join(f"{k} {v / 1e6:.2f} ms" for k, v in sorted(hist.items())))
         if traces and by_grid:
             out.append(f"# per-grid breakdown of kernels matching {grid_of!r} (workgroups per launch)")
             out.append(f"{'kernel':60s} {'workgroups':>10s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")
