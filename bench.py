@@ -23,9 +23,9 @@ if ROOT not in sys.path:
 SEED = 20230211          # reference default seed (main/trainer.py:21)
 N_CONTEXT = 2            # extra context frames -> cond context 77 + 256*(1+N) tokens
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
-# (2 * 7.955e8 + 4.472e8) KB per clip: profiles/r01_rocprofv3_pmc_{FETCH,WRITE}_SIZE_bench_eager.txt
+# (2 * 7.954e8 + 4.559e8) KB per clip: profiles/r01_rocprofv3_pmc_{FETCH,WRITE}_SIZE_bench_eager.txt
 # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; separate --pmc passes, one clip each)
-TRAFFIC_BYTES_PER_CLIP = (2 * 7.955090e8 + 4.471750e8) * 1024
+TRAFFIC_BYTES_PER_CLIP = (2 * 7.954437e8 + 4.558582e8) * 1024
 
 
 def build_model(device, unet_params=None):
