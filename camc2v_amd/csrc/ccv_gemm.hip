@@ -21,7 +21,17 @@ namespace {
 constexpr int BK = 64;  // K granularity every problem must satisfy (K % 64 == 0)
 
 // epilogue for 4 consecutive output columns n..n+3 of row m (acc already holds the full K sum)
-__device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4]) {
+// compile-time loop: f(std::integral_constant<int, B>), f(<B + S>), ... while < E (accumulator fragments must be indexed
+// by constants, or the whole accumulator array moves to scratch memory)
+template <int B, int E, int S, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + S, E, S>(f);
+    }
+}
+
+__device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, float o[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] *= p.alpha;
     if (p.bias) {
@@ -46,6 +56,10 @@ __device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, f
         const float4 rv = *reinterpret_cast<const float4*>(p.residual + (long)m * p.ldr + n);
         o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
     }
+}
+
+__device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4]) {
+    epilogue_math(p, m, n, o);
     if (p.out_f32) {
         *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
@@ -54,8 +68,36 @@ __device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, f
     }
 }
 
+// bf16 outputs, two 16-column fragments side by side: the lane holds columns c .. c+3 (a) and c+16 .. c+19 (b) of row m,
+// c = 16-aligned base + 4 fg.  Lanes fg and fg ^ 1 (16 lanes apart, same row) swap one half each, so that every lane
+// stores 8 consecutive bf16 with one 16-byte store instead of two 8-byte ones: half the store instructions and 64
+// contiguous bytes per row and instruction.  (Output stores are issue-bound at the end of a tile.)  All 64 lanes of the
+// wave must call it together with the same row activity per 16-lane row group (rows are per fr = lane & 15: both partners
+// share it).  Needs 16-byte aligned rows (ldc % 8 == 0, aligned C): callers check p_wide.
+__device__ __forceinline__ void store_pair_bf16(uint16_t* crow, int c, uint2 a, uint2 b) {
+    const bool odd = (threadIdx.x >> 4) & 1;
+    const uint2 send = odd ? a : b;
+    uint2 recv;
+    recv.x = (uint32_t)__shfl_xor((int)send.x, 16, 64);
+    recv.y = (uint32_t)__shfl_xor((int)send.y, 16, 64);
+    const uint4 out = odd ? make_uint4(recv.x, recv.y, b.x, b.y) : make_uint4(a.x, a.y, recv.x, recv.y);
+    *reinterpret_cast<uint4*>(crow + (odd ? c + 12 : c)) = out;
+}
+
+__device__ int g_wide_store = 1;   // CCV_GEMM_WIDE_STORE=0 clears it (A/B aid)
+__device__ __forceinline__ bool wide_bf16_ok(const CcvGemm& p) {
+    return !p.out_f32 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && g_wide_store != 0;
+}
+
+__device__ __forceinline__ void epilogue_store_pair(const CcvGemm& p, int m, int n, float o0[4], float o1[4]) {
+    epilogue_math(p, m, n, o0);
+    epilogue_math(p, m, n + 16, o1);
+    store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, make_uint2(pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])),
+                    make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])));
+}
+
 // GEGLU: value columns n..n+3 and gate columns n+16..n+19 of the interleaved weight layout
-__device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, const float a_[4], const float g_[4]) {
+__device__ __forceinline__ uint2 geglu_value(const CcvGemm& p, int n, const float a_[4], const float g_[4]) {
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -63,9 +105,12 @@ __device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, c
         if (p.bias) { a += p.bias[n + r]; g += p.bias[n + 16 + r]; }
         o[r] = a * gelu_erf_f(g);
     }
+    return make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+}
+
+__device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, const float a_[4], const float g_[4]) {
     const int nc = (n >> 5) * 16 + (n & 15);
-    uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = pk;
+    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = geglu_value(p, n, a_, g_);
 }
 
 // BKT = K-slab depth (bf16 elements): 64 -> 128-byte LDS rows, 2 MFMA k-steps per slab, 64 KiB of LDS for a
@@ -458,10 +503,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
         __syncthreads();
     }
 
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    const bool wide = wide_bf16_ok(p);
+    static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {   // (a plain loop this large is not unrolled any more)
+        constexpr int i = decltype(I)::value;
         const int m = m0 + wm * 16 * MT + 16 * i + fr;
-        if (m >= p.M) continue;
+        if (m >= p.M) return;
         if (p.split_k > 1) {
             float* wsp = static_cast<float*>(p.ws) + ((long)split * p.M + m) * p.N;
 #pragma unroll
@@ -469,27 +515,53 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
                 const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
                 if (n < p.N) *reinterpret_cast<float4*>(wsp + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
-            continue;
+            return;
         }
-        if (p.geglu) {
-#pragma unroll
-            for (int j = 0; j < NT; j += 2) {
-                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
-                if (n >= p.N) continue;
-                const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                epilogue_geglu(p, m, n, a_, g_);
-            }
-            continue;
+        if (NT % 2 == 0 && p.geglu) {
+            static_for<0, NT, 4>([&](auto J) __attribute__((always_inline)) {   // (value, gate) fragment pairs, two pairs at a time
+                constexpr int j = decltype(J)::value;
+                if constexpr (j + 1 < NT) {
+                    const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+                    if (n < p.N) {
+                        const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                        if constexpr (j + 3 < NT) {
+                            const float a2[4] = {acc[i][j + 2][0], acc[i][j + 2][1], acc[i][j + 2][2], acc[i][j + 2][3]};
+                            const float g2[4] = {acc[i][j + 3][0], acc[i][j + 3][1], acc[i][j + 3][2], acc[i][j + 3][3]};
+                            if (wide && n - 4 * fg + 64 <= p.N) {   // both output groups in range: one 16-byte store per lane
+                                store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, (n >> 5) * 16 + (n & 15),
+                                                geglu_value(p, n, a_, g_), geglu_value(p, n + 32, a2, g2));
+                            } else {
+                                epilogue_geglu(p, m, n, a_, g_);
+                                if (n + 32 < p.N) epilogue_geglu(p, m, n + 32, a2, g2);
+                            }
+                        } else {
+                            epilogue_geglu(p, m, n, a_, g_);
+                        }
+                    }
+                }
+            });
+            return;
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        static_for<0, NT, 2>([&](auto J) __attribute__((always_inline)) {   // fragments two at a time
+            constexpr int j = decltype(J)::value;
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
-            if (n >= p.N) continue;
-            float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue_store(p, m, n, o);
-        }
-    }
+            if (n < p.N) {
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (j + 1 < NT) {
+                    float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                    if (wide && n - 4 * fg + 32 <= p.N) {   // bf16 out, both fragments in range: one 16-byte store per lane
+                        epilogue_store_pair(p, m, n, o, o1);
+                    } else {
+                        epilogue_store(p, m, n, o);
+                        if (n + 16 < p.N) epilogue_store(p, m, n + 16, o1);
+                    }
+                } else {
+                    epilogue_store(p, m, n, o);
+                }
+            }
+        });
+    });
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -667,10 +739,11 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    const bool wide = wide_bf16_ok(p);
+    static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {   // (a plain loop this large is not unrolled any more)
+        constexpr int i = decltype(I)::value;
         const int m = m0 + wm * 16 * MT + 16 * i + fr;
-        if (m >= p.M) continue;
+        if (m >= p.M) return;
         if (p.split_k > 1) {
             float* wsp = static_cast<float*>(p.ws) + ((long)split * p.M + m) * p.N;
 #pragma unroll
@@ -678,25 +751,49 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
                 const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
                 *reinterpret_cast<float4*>(wsp + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
-            continue;
+            return;
         }
-        if (NT % 2 == 0 && p.geglu) {
-#pragma unroll
-            for (int j = 0; j + 1 < NT; j += 2) {
-                const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
-                const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                epilogue_geglu(p, m, n, a_, g_);
-            }
-            continue;
+        if (NT % 2 == 0 && p.geglu) {   // N is a multiple of the tile width here: every fragment is in range
+            static_for<0, NT, 4>([&](auto J) __attribute__((always_inline)) {   // (value, gate) fragment pairs, two pairs at a time
+                constexpr int j = decltype(J)::value;
+                if constexpr (j + 1 < NT) {
+                    const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+                    const float a_[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    const float g_[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                    if constexpr (j + 3 < NT) {
+                        const float a2[4] = {acc[i][j + 2][0], acc[i][j + 2][1], acc[i][j + 2][2], acc[i][j + 2][3]};
+                        const float g2[4] = {acc[i][j + 3][0], acc[i][j + 3][1], acc[i][j + 3][2], acc[i][j + 3][3]};
+                        if (wide) {
+                            store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, (n >> 5) * 16 + (n & 15),
+                                            geglu_value(p, n, a_, g_), geglu_value(p, n + 32, a2, g2));
+                        } else {
+                            epilogue_geglu(p, m, n, a_, g_);
+                            epilogue_geglu(p, m, n + 32, a2, g2);
+                        }
+                    } else {
+                        epilogue_geglu(p, m, n, a_, g_);
+                    }
+                }
+            });
+            return;
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        static_for<0, NT, 2>([&](auto J) __attribute__((always_inline)) {   // fragments two at a time
+            constexpr int j = decltype(J)::value;
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
             float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue_store(p, m, n, o);
-        }
-    }
+            if constexpr (j + 1 < NT) {
+                float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                if (wide) {
+                    epilogue_store_pair(p, m, n, o, o1);
+                } else {
+                    epilogue_store(p, m, n, o);
+                    epilogue_store(p, m, n + 16, o1);
+                }
+            } else {
+                epilogue_store(p, m, n, o);
+            }
+        });
+    });
 }
 
 // split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
@@ -903,7 +1000,7 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     // per CU): fewer operand bytes per flop than 128x64 / 64x64 and faster delivery than the ring tiles' 64-byte rows
     // (tools/probes/l2_lds_probe.hip: 19-25 TB/s against 14-16 TB/s into LDS).  The kernel-level sweep (tools/ring_probe.py)
     // favours them on most 32x32- and 16x16-latent shapes, but IN THE MODEL (kernel-time totals of rocprofv3 traces of
-    // bench.py, same box, tools/ab_f160.sh) only two rules pay: the 3x3 / temporal convolutions at 32x32 latents (-0.5 %
+    // bench.py, same box, tools/ab_env.sh CCV_GEMM_F160) only two rules pay: the 3x3 / temporal convolutions at 32x32 latents (-0.5 %
     // of all kernel time) and the long-K layers at 8x8 latents with split-K 4 (-0.7 %); on the 32x32-latent linear
     // layers the GEMMs gain nothing and the kernels that consume their outputs get slower (+17 ms per 77 steps).
     static const bool f160_on = [] { const char* e = getenv("CCV_GEMM_F160"); return !(e && e[0] == '0'); }();   // A/B aid
@@ -1008,6 +1105,15 @@ extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
 
 extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_gemm: null params");
+    static const bool wide_init = [] {
+        const char* e = getenv("CCV_GEMM_WIDE_STORE");
+        if (e && e[0] == '0') {
+            const int zero = 0;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_store), &zero, sizeof(int));
+        }
+        return true;
+    }();
+    (void)wide_init;
     CcvGemm p = *pp;
     Plan pl{-1, 1};
     if (plan_ok(p)) {   // split-K only when the caller provided the workspace ccv_gemm_ws_bytes() asks for
