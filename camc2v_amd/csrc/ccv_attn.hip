@@ -340,8 +340,13 @@ __device__ __forceinline__ void attn_block_coords(int nq, int H, int& qblk, int&
     b = t / H;
 }
 
-template <bool MASKED>
+// TWO: a second context (k2 / v2 / Lk2, the gated image tokens of the cross-attention, attention.py:205-209) with a softmax
+// of its own follows the first in the same tile sequence: when the first tile of the second context comes up, the
+// normalised result of the first is parked as packed bf16 (32 registers) and the running max / sum / accumulators start
+// over; the epilogue writes o1 + gate2 * o2.  Unmasked calls only.
+template <bool MASKED, bool TWO = false>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
+    static_assert(!(MASKED && TWO), "the two-context form has no mask path");
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 
     const int n_reg = (p.kreg != nullptr && p.nreg > 0) ? 1 : 0;
     const int n_main = (p.Lk + KT - 1) / KT;
-    const int n_total = n_reg + n_main;
+    const int n_first = n_reg + n_main;                       // tiles of the first softmax
+    const int n_total = n_first + (TWO ? (p.Lk2 + KT - 1) / KT : 0);
     constexpr bool masked = MASKED;
     const uint8_t* flags = (masked && p.tile_flags) ? p.tile_flags + (long)(b % p.mask_nb) * p.flags_bs : nullptr;
     const int fq0 = 2 * qblk, fq1 = min(2 * qblk + 1, (p.Lq + 127) / 128 - 1);
@@ -388,6 +394,11 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         long kls, vls;
         int len, k0;
         if (it < n_reg) { kb_ = p.kreg + head * 64; vb_ = p.vreg + head * 64; kls = vls = (long)p.H * 64; len = p.nreg; k0 = 0; }
+        else if (TWO && it >= n_first) {
+            kb_ = p.k2 + bo * p.k2_bso + bi * p.k2_bsi + head * 64;
+            vb_ = p.v2 + bo * p.v2_bso + bi * p.v2_bsi + head * 64;
+            kls = p.k2_ls; vls = p.v2_ls; len = p.Lk2; k0 = (it - n_first) * KT;
+        }
         else { kb_ = kmain; vb_ = vmain; kls = p.k_ls; vls = p.v_ls; len = p.Lk; k0 = (it - n_reg) * KT; }
         unsigned char* sK = sm + stage * (2 * KT * 128);
         unsigned char* sV = sK + KT * 128;
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
             const int piece = wave * 2 + j;             // 8 rows of 128 B
             const int row = 8 * piece + (lane >> 3), pc = lane & 7;
             const bool ok = (k0 + row) < len;
-            const long krow_g = (it < n_reg) ? (long)(k0 + row) : (long)ccv_patch_row(k0 + row, p.perm_hw, p.perm_w);
+            const long krow_g = (it < n_reg || (TWO && it >= n_first)) ? (long)(k0 + row) : (long)ccv_patch_row(k0 + row, p.perm_hw, p.perm_w);
             const uint16_t* gk = ok ? kb_ + krow_g * kls + ((pc ^ ((row >> 1) & 7)) << 3) : zero;
             const uint16_t* gv = ok ? vb_ + krow_g * vls + ((pc ^ (((row >> 1) & 1) << 2)) << 3) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t*)gk, (lptr_t*)(sK + piece * 1024), 16, 0, 0);
@@ -413,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
 
+    uint32_t o1pk[TWO ? 2 : 1][2][8];   // first context's normalised output, packed bf16 pairs
     // mask words of a tile: [query block][32-key block]; loaded one tile ahead so their latency hides behind
     // the current tile's math (register tokens and unmasked calls see all-ones)
     auto load_words = [&](int it, uint32_t (&w)[2][2]) {
@@ -447,10 +459,28 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         if (nxt < n_total) issue(nxt, stage ^ 1);
         load_words(nxt, mwn);
 
+        if (TWO && cur == n_first) {   // block-uniform: park the first softmax's result, start the second
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+                const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o1pk[TWO ? qb : 0][d][e] = pack_bf16x2(oacc[qb][d][2 * e] * wgt, oacc[qb][d][2 * e + 1] * wgt);
+                        oacc[qb][d][2 * e] = 0.f;
+                        oacc[qb][d][2 * e + 1] = 0.f;
+                    }
+                m_run[qb] = NEG_INF;
+                l_run[qb] = 0.f;
+            }
+        }
         if (wave_active) {
             const bool is_reg = cur < n_reg;
-            const int k0 = is_reg ? 0 : (cur - n_reg) * KT;
-            const int nvalid = min(KT, (is_reg ? p.nreg : p.Lk) - k0);
+            const bool second = TWO && cur >= n_first;
+            const int k0 = is_reg ? 0 : (second ? (cur - n_first) * KT : (cur - n_reg) * KT);
+            const int nvalid = min(KT, (is_reg ? p.nreg : (second ? p.Lk2 : p.Lk)) - k0);
             const unsigned char* sK = sm + stage * (2 * KT * 128);
             const unsigned char* sV = sK + KT * 128;
             uint32_t mw[2][2];
@@ -545,8 +575,16 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int dd = 32 * d + 8 * g4 + 4 * hh;
-                    uint2 pk = make_uint2(pack_bf16x2(oacc[qb][d][4 * g4] * wgt, oacc[qb][d][4 * g4 + 1] * wgt),
-                                          pack_bf16x2(oacc[qb][d][4 * g4 + 2] * wgt, oacc[qb][d][4 * g4 + 3] * wgt));
+                    float o0 = oacc[qb][d][4 * g4] * wgt, o1 = oacc[qb][d][4 * g4 + 1] * wgt;
+                    float o2 = oacc[qb][d][4 * g4 + 2] * wgt, o3 = oacc[qb][d][4 * g4 + 3] * wgt;
+                    if (TWO) {
+                        const uint32_t a = o1pk[TWO ? qb : 0][d][2 * g4], c = o1pk[TWO ? qb : 0][d][2 * g4 + 1];
+                        o0 = bf16_to_f32((uint16_t)(a & 0xffffu)) + p.gate2 * o0;
+                        o1 = bf16_to_f32((uint16_t)(a >> 16)) + p.gate2 * o1;
+                        o2 = bf16_to_f32((uint16_t)(c & 0xffffu)) + p.gate2 * o2;
+                        o3 = bf16_to_f32((uint16_t)(c >> 16)) + p.gate2 * o3;
+                    }
+                    uint2 pk = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
                     *reinterpret_cast<uint2*>(op + dd) = pk;
                 }
         }
@@ -880,6 +918,11 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
 
 }  // namespace
 
+static bool two_ctx_on() {   // CCV_ATTN_TWO=0: two-context calls on the first-generation kernel (A/B aid)
+    static const bool v = [] { const char* e = getenv("CCV_ATTN_TWO"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_attn_fwd: null params");
     const CcvAttn& p = *pp;
@@ -932,6 +975,10 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL(attn2_kernel<false>, grid2, dim3(256), 0, st, p);
+    } else if (p.variant == 0 && p.k2 && !p.mask_bits && p.perm_w == 0 && two_ctx_on()) {   // two contexts (text + gated image tokens)
+        const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
+        CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
+        hipLaunchKernelGGL((attn2_kernel<false, true>), dim3((unsigned)nwg2), dim3(256), 0, st, p);
     } else if (p.variant == 0 || p.variant == 1)
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, p);
     else

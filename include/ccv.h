@@ -151,7 +151,7 @@ typedef struct CcvAttn {
     int32_t perm_hw, perm_w; /* token order of q/k/v/o rows and of the mask: 0 = as stored; otherwise the kernel walks each
                               * frame (perm_hw tokens, perm_w wide) in 4x8-pixel patches (index -> row map in ccv_patch_row);
                               * the mask must have been built with the same values */
-    int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; two-context calls use kernel 1);
+    int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; unmasked two-context calls run both softmaxes in it);
                          1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging;
                          3: as 0 but always the per-wave sparse kernel when wave_bits is given (0 picks it from 1024
                             64-query groups upwards and the tiled masked kernel below that) */

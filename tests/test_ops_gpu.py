@@ -336,6 +336,31 @@ def test_attention_fused_qkv_and_dual_context(ops, variant):
     assert_close(out.reshape(B, hw, H, 64), ref, 1.5e-2, "dual context")
 
 
+@pytest.mark.parametrize("Lq,Lk2,per_frame", [(1024, 768, False), (256, 256, False), (1024, 16, True), (200, 100, False), (64, 333, False)])
+def test_attention_dual_context_shapes(ops, Lq, Lk2, per_frame):
+    """Two-context cross-attention (77 text tokens + gated image tokens, separate softmaxes) in the LDS-DMA kernel at the
+    model's shapes: image tokens shared by the frames of a clip or 16 per frame, ragged lengths, several clips."""
+    clips, frames, H = 2, 4, 5
+    C = H * 64
+    B = clips * frames
+    q = rnd(B * Lq, C, seed=124)
+    kv_t = rnd(clips * 77, 2 * C, seed=125)
+    n_img = clips * (frames if per_frame else 1) * Lk2
+    kv_i = rnd(n_img, 2 * C, seed=126)
+    gate = 0.83
+    st_i = (frames * Lk2 * 2 * C, Lk2 * 2 * C, 2 * C) if per_frame else (Lk2 * 2 * C, 0, 2 * C)
+    out = ops.attention(q, kv_t, kv_t[:, C:], B=B, inner=frames, H=H, Lq=Lq, Lk=77,
+                        q_str=(frames * Lq * C, Lq * C, C), k_str=(77 * 2 * C, 0, 2 * C), v_str=(77 * 2 * C, 0, 2 * C),
+                        k2=kv_i, v2=kv_i[:, C:], k2_str=st_i, v2_str=st_i, Lk2=Lk2, gate2=gate)
+    qf = q.float().reshape(B, Lq, H, 64)
+    kt = kv_t.float().reshape(clips, 77, 2, H, 64).repeat_interleave(frames, 0)
+    ki = kv_i.float().reshape(-1, Lk2, 2, H, 64)
+    if not per_frame:
+        ki = ki.repeat_interleave(frames, 0)
+    ref = ref_attn(qf, kt[:, :, 0], kt[:, :, 1]) + gate * ref_attn(qf, ki[:, :, 0], ki[:, :, 1])
+    assert_close(out.reshape(B, Lq, H, 64), ref, 1.5e-2, f"dual context Lq={Lq} Lk2={Lk2} per_frame={per_frame}")
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("T", [16, 9])
 def test_attention_temporal_strided(ops, variant, T):
