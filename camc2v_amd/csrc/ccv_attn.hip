@@ -923,9 +923,28 @@ static bool two_ctx_on() {   // CCV_ATTN_TWO=0: two-context calls on the first-g
     return v;
 }
 
+// Inner batches that share their keys and values (k/v inner-batch stride 0: the frames of a clip against the clip's text /
+// image tokens) and whose queries and outputs lie back to back are one longer query sequence: a workgroup then fills its
+// four waves with 256 queries from several frames and streams the shared K/V tiles once for all of them (at 8x8 latents a
+// frame has 64 queries: one active wave per workgroup and 16x the K/V traffic otherwise).  CCV_ATTN_FOLD=0 disables it.
+static CcvAttn fold_shared_kv(const CcvAttn& in) {
+    static const bool on = [] { const char* e = getenv("CCV_ATTN_FOLD"); return !(e && e[0] == '0'); }();
+    CcvAttn p = in;
+    const bool shared = p.k_bsi == 0 && p.v_bsi == 0 && (!p.k2 || (p.k2_bsi == 0 && p.v2_bsi == 0));
+    if (on && shared && p.inner > 1 && p.B % p.inner == 0 && !p.mask_bits && !p.kreg && p.perm_w == 0 && p.variant == 0 &&
+        p.q_bsi == (int64_t)p.Lq * p.q_ls && p.o_bsi == (int64_t)p.Lq * p.o_ls && (long)p.inner * p.Lq < (1l << 30) && p.Lq > 16) {
+        p.Lq *= p.inner;
+        p.B /= p.inner;
+        p.inner = 1;
+        p.q_bsi = p.o_bsi = 0;
+    }
+    return p;
+}
+
 extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_attn_fwd: null params");
-    const CcvAttn& p = *pp;
+    const CcvAttn p_folded = fold_shared_kv(*pp);
+    const CcvAttn& p = p_folded;
     CCV_REQUIRE(p.q && p.k && p.v && p.o, CCV_EINVAL, "ccv_attn_fwd: null q/k/v/o");
     CCV_REQUIRE(p.B > 0 && p.H > 0 && p.Lq > 0 && p.Lk > 0 && p.inner > 0, CCV_EINVAL,
                 "ccv_attn_fwd: non-positive B/H/Lq/Lk/inner (%d,%d,%d,%d,%d)", p.B, p.H, p.Lq, p.Lk, p.inner);
