@@ -2,15 +2,26 @@
 """Benchmark of the hot path: 25-step DDIM sampling with classifier-free guidance of CamContextI2V-256
 clips (1 x 16 x 256 x 256, CFG 7.5, guidance rescale 0.7, eta 1) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input = one full 25-step DDIM sampling of
-one clip per GPU (50 UNet forwards' worth of work, run as 25 batched cond+uncond forwards).  Inputs are
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line (see the driver contract).
+one clip per GPU (50 UNet forwards' worth of work, run as 25 batched cond+uncond forwards).  EVERY clip has its
+own conditioning tensors (text / image tokens, context latents, Pluecker features, fundamental matrices and masks,
+start noise), all resident in HBM before the timed region; the once-per-clip work the sampler does with them (copy
+into the hipGraph's static buffers, context K/V projections of the 16 cross-attention layers, Pluecker rows) is
+inside the timed region.  Rank 0 prints ONE JSON line (see the driver contract).
+
+N > 1: one process per GPU.  Started by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) it joins the job; started plainly with `--gpus N` it launches that command itself as a CHILD process
+before touching the GPU and relays the child's JSON line.  Clips shard across ranks with no collective on the data
+path (`scaling: weak`); one RCCL all_gather of the final latents closes the timed region so that the line can
+report how many ranks took part.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,9 +34,7 @@ if ROOT not in sys.path:
 SEED = 20230211          # reference default seed (main/trainer.py:21)
 N_CONTEXT = 2            # extra context frames -> cond context 77 + 256*(1+N) tokens
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
-# (2 * 7.954e8 + 4.559e8) KB per clip: profiles/r01_rocprofv3_pmc_{FETCH,WRITE}_SIZE_bench_eager.txt
-# (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; separate --pmc passes, one clip each)
-TRAFFIC_BYTES_PER_CLIP = (2 * 7.954437e8 + 4.558582e8) * 1024
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # PMC-derived bytes of this round's profile run
 
 
 def build_model(device, unet_params=None):
@@ -45,10 +54,10 @@ def build_model(device, unet_params=None):
     return model
 
 
-def synthetic_inputs(model, device, b=1, t=16, hl=32, rank=0):
-    """SURVEY.md section 8(d) synthetic clip."""
+def synthetic_inputs(model, device, b=1, t=16, hl=32, rank=0, clip=0):
+    """SURVEY.md section 8(d) synthetic clip; (rank, clip) select the random draws, the camera trajectory is the fixed one."""
     from camc2v_amd import camera
-    g = torch.Generator(device=device).manual_seed(SEED + 17 * rank)
+    g = torch.Generator(device=device).manual_seed(SEED + 17 * rank + 1009 * clip)
     rn = lambda *s: torch.randn(*s, device=device, generator=g)
     ctx_dim = 1024
     img = torch.nn.functional.layer_norm(rn(b, 256 * (1 + N_CONTEXT), ctx_dim), (ctx_dim,))
@@ -80,48 +89,58 @@ def sample_clip(model, cond, uncond, fs, x_T, noises, use_graph):
     return samples
 
 
-def cpu_baseline(model, device):
-    """Oracle (CPU restatement, fp32) timed on the host cores on ONE UNet forward of the reference's
-    CPU-runnable case (no camera, ctx 77+16t): bounded sample, ~10-30 s.  Also reports the full-size
-    eps parity of the HIP path on exactly that forward."""
-    from oracle import unet_oracle
-    from camc2v_amd import configs
-    unet = model.model.diffusion_model
-    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-    g = torch.Generator().manual_seed(SEED)
-    x = torch.randn(1, 8, 16, 32, 32, generator=g)
-    ctx = torch.randn(1, 77 + 256, 1024, generator=g)
-    ctx_cond = torch.randn(1, 77 + 256 * (1 + N_CONTEXT), 1024, generator=g)    # the conditional pass's context length
-    t = torch.tensor([439])
-    fs = torch.tensor([8])
+def host_cores():
     # the GPU box gives a 1-GPU job a share of 16 host cores; more threads than that only oversubscribe
-    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(16, n))
+
+
+def cpu_baseline(model, device, inputs):
+    """The oracle (fp32 CPU restatement of the reference's UNet) timed on the host cores on the metric's own workload:
+    ONE classifier-free-guidance step of the benchmark clip = the camera-conditioned conditional forward (context 77 +
+    768 tokens) + the camera-conditioned unconditional forward (77 + 256), same weights, inputs and epipolar masks as
+    the GPU run (bounded sample: 2 of the clip's 50 forwards).  The same two outputs give the full-size parity of the
+    HIP path (`apply_model_pair`, what the sampler runs)."""
+    from oracle import geometry_oracle, unet_oracle
+    from camc2v_amd import configs
+    cond, uncond, fs, x_T, _ = inputs
+    unet = model.model.diffusion_model
+    t = torch.full((1,), 439, dtype=torch.long, device=device)
+    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True))
+    with torch.no_grad():
+        e_c, e_uc = model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)
+    e_c, e_uc = e_c.float().cpu(), e_uc.float().cpu()
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    cam = cond["camera_condition"]
+    F = cam["fundamental"].float().cpu()
+    masks = {d: geometry_oracle.epipolar_mask(F, 256 // d, 256 // d, d) for d in (8, 16, 32, 64)}
+    cam_cpu = dict(pluker_embedding_features=[f.float().cpu() for f in cam["pluker_embedding_features"]],
+                   sample_locs_dict=masks, add_type=cam["add_type"])
+    x = torch.cat([x_T, cond["c_concat"][0]], 1).float().cpu()
+    cores = host_cores()
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ref = unet_oracle.unet_forward(sd, configs.UNET_256, x, t, ctx, fs, None)
-    dt_u = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        unet_oracle.unet_forward(sd, configs.UNET_256, x, t, ctx_cond, fs, None)
-    dt_c = time.perf_counter() - t0
-    with torch.no_grad():
-        got = unet(x.to(device), t.to(device), context=ctx.to(device), fs=fs.to(device)).float().cpu()
-    rel_l2 = ((got - ref).norm() / ref.norm()).item()
-    max_rel = ((got - ref).abs().max() / ref.abs().max()).item()
-    # the metric's clip needs 25 x (cond + uncond) forwards; the camera-conditioned forwards of the metric cost more than
-    # these two (Pluecker projections + 2 TF of epipolar attention each), so this is an upper bound for the CPU
-    value = 16.0 / (25.0 * (dt_u + dt_c))
+    secs, parity = [], {}
+    for got, ctx, what in ((e_c, cond["c_crossattn"][0], "cond"), (e_uc, uncond["c_crossattn"][0], "uncond")):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref = unet_oracle.unet_forward(sd, configs.UNET_256, x, t.cpu(), ctx.float().cpu(), fs.cpu(), cam_cpu, origin_h=256)
+        secs.append(time.perf_counter() - t0)
+        parity[f"{what}_rel_l2"] = ((got - ref).norm() / ref.norm()).item()
+        parity[f"{what}_max_rel"] = ((got - ref).abs().max() / ref.abs().max()).item()
+    parity["case"] = ("full-size camera-conditioned CFG step (cond ctx 845 + uncond ctx 333, b=1, 32x32 latents, native packed "
+                      "masks) vs the fp32 oracle")
+    value = 16.0 / (25.0 * sum(secs))
     return dict(value=value, unit="frames/s", cores=cores, kind="port",
-                sample=f"2 UNet forwards (no camera, b=1, fp32 oracle): ctx 333 = {dt_u:.2f} s, ctx {ctx_cond.shape[1]} = {dt_c:.2f} s; "
-                       f"value = 16 frames / (25 x their sum), an upper bound for the CPU on the CFG+camera clip",
-                seconds_per_forward=0.5 * (dt_u + dt_c)), dict(rel_l2=rel_l2, max_rel=max_rel, case="full-size UNet forward, no camera, vs fp32 oracle")
+                sample=f"1 of the clip's 25 CFG steps = 2 camera-conditioned UNet forwards (fp32 oracle, b=1): cond ctx 845 = "
+                       f"{secs[0]:.2f} s, uncond ctx 333 = {secs[1]:.2f} s; value = 16 frames / (25 x their sum)",
+                seconds_per_cfg_step=sum(secs)), parity
 
 
-def timed_clips(sample_fn, steps, warmup, dist=None, sync=None):
-    """W untimed + exactly K timed calls of `sample_fn`, bracketed by sync + barrier + sync on both sides;
-    returns (max-over-ranks wall seconds, this rank's wall seconds, last output).  Device independent so the
-    multi-process logic is testable on CPU with gloo."""
+def timed_clips(sample_fn, steps, warmup, dist=None, sync=None, after=None):
+    """W untimed + exactly K timed calls of `sample_fn(i)`, bracketed by sync + barrier + sync on both sides;
+    `after(last_output)` (the final all_gather) runs inside the timed region.  Returns (max-over-ranks wall seconds,
+    this rank's wall seconds, last output, after's result).  Device independent so the multi-process logic is testable
+    on CPU with gloo."""
     sync = sync or (lambda: None)
 
     def fence():
@@ -130,135 +149,269 @@ def timed_clips(sample_fn, steps, warmup, dist=None, sync=None):
             dist.barrier()
         sync()
 
-    for _ in range(warmup):
-        sample_fn()
+    for i in range(warmup):
+        sample_fn(i)
     fence()
     t0 = time.perf_counter()
     out = None
-    for _ in range(steps):
-        out = sample_fn()
+    for i in range(steps):
+        out = sample_fn(warmup + i)
+    extra = after(out) if after is not None else None
     fence()
     mine = time.perf_counter() - t0
     worst = mine
     if dist is not None:
         tt = torch.tensor([mine], dtype=torch.float64)
-        if sync is not None and torch.cuda.is_available() and dist.get_backend() == "nccl":
+        if torch.cuda.is_available() and dist.get_backend() == "nccl":
             tt = tt.cuda()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         worst = float(tt.item())
-    return worst, mine, out
+    return worst, mine, out, extra
 
 
-def dominant_kernel(device, launches=50):
-    """The GEMM instantiation with the largest share of the clip (profiles/r01_rocprofv3_kernel_stats_bench_graph.txt):
-    gemm_dma_kernel<4, 2, 0> (128x64 tiles: the N = 320 / 960 projections at 32x32 latents), timed live on the fused QKV
-    projection,
-    M = 2 clips x 16 frames x 1024 tokens, N = 3 x 320, K = 320 -- with HIP events around a hipGraph of `launches`
-    back-to-back launches on the current stream (algorithmic FLOPs 2 M N K per launch)."""
+def gather_latents(dist, world):
+    """after-hook of the timed region: all_gather of the final latents (128 KB per rank); returns the number of ranks whose
+    latents arrived finite and distinct."""
+    def run(out):
+        if dist is None:
+            return 1
+        parts = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(parts, out.contiguous())
+        sums = [float(p.double().abs().sum()) for p in parts]
+        return len({round(s, 3) for s in sums if s == s and s != float("inf")})
+    return run
+
+
+# ---- the dominant kernel, timed live ---------------------------------------------------------------------------------
+def dominant_kernel(model, device, inputs, reps=20):
+    """attn_sparse_kernel (largest share of kernel time in the rocprofv3 trace of this command): the masked epipolar
+    attention of the 5 + 5 temporal blocks at 32x32 and 16x16 latents of one CFG step (b = 2: cond + uncond), on the
+    benchmark clip's own masks, timed with HIP events on the launch stream around a hipGraph of those 10 launches.
+    Algorithmic FLOPs per launch by SURVEY.md section 8(d)'s dense convention (4 Lq Lk 64 H b, mask ignored), and the
+    executed share (32-key blocks the kernel visits / all blocks) beside it."""
     from camc2v_amd import ops
-    M, N, K = 32768, 960, 320
+    cam = inputs[0]["camera_condition"]["sample_locs_packed"]
     g = torch.Generator(device=device).manual_seed(SEED)
-    a = torch.randn(M, K, device=device, generator=g).to(torch.bfloat16)
-    w = (torch.randn(N, K, device=device, generator=g) * 0.05).to(torch.bfloat16)
-    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    fn = lambda: ops.gemm(a, w, out=out)
+    calls, flops, visited = [], [], []
+    for d, hl, H in ((8, 32, 5), (16, 16, 10)):
+        bits, flags, perm, wbits, order = cam[d]
+        L = 16 * hl * hl
+        qkv = torch.randn(2 * L, 3 * H * 64, device=device, generator=g).to(torch.bfloat16)
+        kreg = torch.randn(4, H * 64, device=device, generator=g).to(torch.bfloat16)
+        s = (L * 3 * H * 64, 0, 3 * H * 64)
+        out = torch.empty(2 * L, H * 64, device=device, dtype=torch.bfloat16)
+        kw = dict(B=2, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s, mask_bits=bits, tile_flags=flags, mask_nb=bits.shape[0],
+                  wave_bits=wbits, group_order=order, perm=perm, kreg=kreg, vreg=kreg, out=out, o_str=(L * H * 64, 0, H * 64))
+        calls.append((qkv, H, kw))
+        flops.append(4.0 * L * L * 64 * H * 2)
+        nblk = (L + 31) // 32
+        words = wbits.reshape(-1).to(torch.int64) & 0xFFFFFFFF
+        pop = sum(int(((words >> i) & 1).sum()) for i in range(32))
+        visited.append(pop / (wbits.shape[0] * wbits.shape[1] * nblk))
+
+    def run():
+        for qkv, H, kw in calls:
+            for _ in range(5):
+                ops.attention(qkv, qkv[:, H * 64:], qkv[:, 2 * H * 64:], **kw)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        fn()
+        run()
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        for _ in range(launches):
-            fn()
+        run()
     graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    graph.replay()
+    for _ in range(reps):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / launches
-    tf = 2.0 * M * N * K / us / 1e6
-    return {"kernel": "gemm_dma_kernel<4, 2, 0>", "problem": f"QKV projection M={M} N={N} K={K} (bf16 in/out)",
-            "flops_per_launch": 2.0 * M * N * K, "us_per_launch": us, "achieved": tf, "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS}
+    us = e0.elapsed_time(e1) * 1e3 / (reps * 10)
+    fl = 0.5 * (flops[0] + flops[1])                  # mean over the 10 launches
+    fl_exec = 0.5 * (flops[0] * visited[0] + flops[1] * visited[1])
+    tf = fl / us / 1e6
+    return dict(kernel="attn_sparse_kernel", us_per_launch=us, flops_per_launch=fl, achieved=tf, frac=tf / PEAK_BF16_TFLOPS,
+                executed_fraction=fl_exec / fl, effective_tflops=fl_exec / us / 1e6,
+                problem="masked epipolar attention, b=2 (cond+uncond), L=16384 H=5 (x5) and L=4096 H=10 (x5) per CFG step, 4 register "
+                        "tokens, benchmark masks; dense FLOP convention 4 Lq Lk 64 H b",
+                visited_block_fraction={"32x32": visited[0], "16x16": visited[1]})
 
 
-def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None):
+def skipped_flops(inputs):
+    """TFLOP per clip that the reference's dense count (375) contains and this path does not execute: the masked-out 32-key
+    blocks of the epipolar attention (counted from the clip's own block bitmaps) and the per-step, per-frame context K/V
+    projections (done once per clip here)."""
+    cam = inputs[0]["camera_condition"]["sample_locs_packed"]
+    epi = 0.0
+    for d, hl, H, nblocks in ((8, 32, 5, 5), (16, 16, 10, 5), (32, 8, 20, 5), (64, 4, 20, 1)):
+        wbits = cam[d][3]
+        L = 16 * hl * hl
+        words = wbits.reshape(-1).to(torch.int64) & 0xFFFFFFFF
+        pop = sum(int(((words >> i) & 1).sum()) for i in range(32))
+        frac = pop / (wbits.shape[0] * wbits.shape[1] * ((L + 31) // 32))
+        if hl <= 8:
+            frac = 1.0            # small maps run the tiled masked kernel (128x64 tile skipping only): counted as dense
+        epi += nblocks * 4.0 * L * L * 64 * H * (1.0 - frac)
+    epi_clip = epi * 2 * 25 / 1e12                      # both CFG halves, 25 steps
+    sum_c = 5 * 320 + 5 * 640 + 6 * 1280                # the 16 cross-attention layers' widths
+    kv_ref = 25 * sum(4.0 * 16 * L * 1024 * sum_c for L in (77 + 256 * (1 + N_CONTEXT), 77 + 256)) / 1e12
+    kv_here = (4.0 * (77 + 256 * (1 + N_CONTEXT)) * 1024 * sum_c + 4.0 * (77 + 16 * 16) * 1024 * sum_c) / 1e12
+    return epi_clip, kv_ref - kv_here
+
+
+def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None):
     from camc2v_amd import configs
     clips = steps * world
     tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
     per_clip_s = (dev_ms / 1e3 / steps) if dev_ms is not None else elapsed / steps
     achieved = tf_per_clip / per_clip_s  # one GPU's rate: algorithmic TFLOP of a clip / its device time
-    return {
+    whole = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+             "algorithmic_tflop_per_clip": tf_per_clip, "device_ms_per_clip": 1e3 * per_clip_s,
+             "note": "all launches of 25 CFG steps; reference's dense FLOP count (masks ignored, context K/V per step and frame)"}
+    if skipped is not None:
+        epi, kv = skipped
+        eff = (tf_per_clip - epi - kv) / per_clip_s
+        whole.update(executed_tflop_per_clip=tf_per_clip - epi - kv, effective_achieved=eff, effective_frac=eff / PEAK_BF16_TFLOPS,
+                     skipped={"epipolar_masked_blocks_tflop": epi, "context_kv_reprojection_tflop": kv,
+                              "fraction_of_dense": (epi + kv) / tf_per_clip})
+    roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None}
+    if dom is not None:
+        roof.update(achieved=dom["achieved"], frac=dom["frac"], kernel=dom["kernel"], us_per_launch=dom["us_per_launch"],
+                    flops_per_launch=dom["flops_per_launch"], executed_fraction=dom["executed_fraction"],
+                    effective_tflops=dom["effective_tflops"], problem=dom["problem"],
+                    visited_block_fraction=dom["visited_block_fraction"])
+    if os.path.exists(TRAFFIC_FILE):     # HBM-side bytes per launch of the dominant kernel from this round's PMC passes
+        try:
+            tr = json.load(open(TRAFFIC_FILE))
+            roof["traffic"] = tr.get("dominant_kernel_bytes_per_launch")
+            roof["traffic_source"] = tr.get("source")
+            whole["traffic_bytes_per_clip"] = tr.get("bytes_per_clip")
+        except (OSError, ValueError):
+            pass
+    roof["whole_path"] = whole
+    line = {
         "metric": "denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
         "value": 16.0 * clips / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, "
-                               "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights",
+                               "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights; every clip "
+                               "has its own conditioning tensors (per-clip prologue inside the timed region)",
                    "clips_per_gpu": 1, "parallelism": f"clip-dp{world}", "launch": "hipGraph" if use_graph else "eager"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": TRAFFIC_BYTES_PER_CLIP,
-                     "kernel": "whole DDIM path (all launches of 25 CFG steps); algorithmic 375 TFLOP/clip, masks counted "
-                               "dense; traffic = L2<->fabric bytes per clip from rocprofv3 PMC passes (profiles/r01_*pmc*): "
-                               "2*FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included",
-                     "device_ms_per_clip": 1e3 * per_clip_s},
+        "roofline": roof,
     }
+    if ranks_seen is not None:
+        line["config"]["ranks_in_final_all_gather"] = ranks_seen
+    return line
 
 
-def main():
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: run the N-rank job as a child process (this process has not touched
+    the GPU and never will) and relay its output and exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None, hooks=None):
+    """hooks (tests only): dict(device=, backend=, build_model=, synthetic_inputs=, sample_clip=, sync=, extras=False) lets the
+    multi-process logic run on CPU with gloo and a stand-in clip."""
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--same-conditioning", action="store_true", help="every clip reuses clip 0's tensors (round-1 behaviour)")
+    args = ap.parse_args(argv)
+    hooks = hooks or {}
 
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return spawn_ranks(args, argv)      # before any GPU call in this process
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+
+    on_gpu = "device" not in hooks
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
+    else:
+        device, sync = hooks["device"], hooks.get("sync", lambda: None)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if not dist.is_initialized():
+            if on_gpu:
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(hooks.get("backend", "gloo"), rank=rank, world_size=world)
 
     torch.set_grad_enabled(False)
-    model = build_model(device)
-    cond, uncond, fs, x_T, noises = synthetic_inputs(model, device, rank=rank)
+    model = hooks.get("build_model", build_model)(device)
+    make_inputs = hooks.get("synthetic_inputs", synthetic_inputs)
+    run_clip = hooks.get("sample_clip", sample_clip)
+    n_sets = 1 if args.same_conditioning else args.steps + args.warmup
+    sets = [make_inputs(model, device, rank=rank, clip=i) for i in range(n_sets)]
     use_graph = not args.no_graph
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    state = {"n": 0}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if on_gpu else None
+    first_ms = {}
 
-    def one_clip():
-        if state["n"] == args.warmup:          # first timed clip: HIP event on the launch stream
-            ev0.record()
-        state["n"] += 1
-        return sample_clip(model, cond, uncond, fs, x_T, noises, use_graph)
+    def one_clip(i):
+        if on_gpu and i == args.warmup:          # first timed clip: HIP event on the launch stream
+            ev[0].record()
+        t0 = time.perf_counter()
+        out = run_clip(model, *sets[i % n_sets], use_graph)
+        if i == 0:
+            sync()
+            first_ms["v"] = 1e3 * (time.perf_counter() - t0)
+        return out
 
-    elapsed, _, out = timed_clips(one_clip, args.steps, args.warmup, dist, torch.cuda.synchronize)
-    ev1.record()
-    torch.cuda.synchronize()
-    dev_ms = ev0.elapsed_time(ev1)
+    elapsed, _, out, ranks_seen = timed_clips(one_clip, args.steps, args.warmup, dist, sync, gather_latents(dist, world))
+    dev_ms = None
+    if on_gpu:
+        ev[1].record()
+        torch.cuda.synchronize()
+        dev_ms = ev[0].elapsed_time(ev[1])
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms)
-        line["roofline"]["dominant_kernel"] = dominant_kernel(device)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["parity_full_size"] = cpu_baseline(model, device)
+        extras = on_gpu and hooks.get("extras", True)
+        dom = dominant_kernel(model, device, sets[0]) if extras else None
+        skipped = skipped_flops(sets[0]) if extras else None
+        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen)
+        if first_ms:
+            line["config"]["first_clip_ms"] = first_ms["v"]    # includes packing, graph capture (a new signature) and caches
+        if world == 1 and extras and not args.no_cpu_baseline:
+            line["cpu_baseline"], line["parity_full_size"] = cpu_baseline(model, device, sets[0])
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        if "device" not in hooks or hooks.get("destroy", True):
+            dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -92,13 +92,36 @@ class LatentDiffusionCore(nn.Module):
         out = self.model(x_noisy, t, **self._as_dict(cond), **kwargs)
         return out[0] if isinstance(out, tuple) else out
 
+    @staticmethod
+    def _same_extras(c, uc):
+        """True when everything besides c_concat / c_crossattn is shared by the two CFG halves: the same objects, or --
+        for the camera dict -- the shallow copy the sampler puts into the unconditional dict (same tensors, plus the
+        'is_uc' marker)."""
+        keys = (set(c) | set(uc)) - {"c_concat", "c_crossattn"}
+        for k in keys:
+            if k not in c or k not in uc:
+                return False
+            a, b = c[k], uc[k]
+            if a is b:
+                continue
+            if k == "camera_condition" and isinstance(a, dict) and isinstance(b, dict):
+                ka = set(a) - {"is_uc"}
+                plain = lambda v: isinstance(v, (str, int, float, bool, type(None)))
+                if ka != set(b) - {"is_uc"} or any(not (a[f] is b[f] or (plain(a[f]) and plain(b[f]) and a[f] == b[f])) for f in ka):
+                    return False
+                continue
+            return False
+        return True
+
     def apply_model_pair(self, x, t, cond, uncond, **kwargs):
         """Conditional and unconditional eps in ONE UNet forward on a 2b batch.  The two contexts may have
         different lengths (cond: 77+256(1+N) tokens, uncond: 77+16t): they are handed over as a list and
         only the cross-attention runs per half.  Everything that is not c_concat / c_crossattn must be
         shared by the two halves (the sampler shares the camera dict; fs and flags come in kwargs)."""
         c, uc = self._as_dict(cond), self._as_dict(uncond)
-        if self.model.conditioning_key != "hybrid":
+        if self.model.conditioning_key != "hybrid" or not self._same_extras(c, uc):
+            # e.g. a conditional dict with a camera but enable_camera_condition off: the reference's second apply_model
+            # then runs WITHOUT the camera (ddim.py:258-263), which one batched forward cannot express
             return self.apply_model(x, t, c, **kwargs), self.apply_model(x, t, uc, **kwargs)
         b = x.shape[0]
         # a single context tensor is handed over as is: the UNet caches its K/V projections by tensor identity

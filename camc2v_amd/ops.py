@@ -406,6 +406,11 @@ def timestep_embedding(t, dim):
 
 def add_silu_bf16(a, b=None):
     _dev(a, b)
+    for t in (a, b):
+        if t is not None and (t.dtype != F32 or not t.is_contiguous()):
+            raise CcvError("add_silu_bf16: contiguous fp32 tensors expected")
+    if b is not None and b.shape != a.shape:
+        raise CcvError(f"add_silu_bf16: shapes differ ({tuple(a.shape)} vs {tuple(b.shape)}); the kernel reads a.numel() elements of both")
     out = torch.empty(a.shape, dtype=BF16, device=a.device)
     check(lib().ccv_add_silu_bf16(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "ccv_add_silu_bf16")
     return out

@@ -64,71 +64,191 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     return sig.float().numpy(), a.numpy(), a_prev.float().numpy()
 
 
-class _GraphedStep:
-    """One CFG DDIM step (batched UNet forward + fused guidance/update) captured into a hipGraph.
+def _unet_of(model):
+    return getattr(getattr(model, "model", None), "diffusion_model", None)
 
-    The ~1.4k kernel launches of a step are replayed with one call; only three tiny device copies
-    (timestep row, coefficient row, noise) precede each replay.  The capture bakes in the device addresses of
-    the conditioning tensors, so graphs are cached on the model keyed by tensor identity and shapes: sampling
-    again with the same conditioning tensors (the benchmark; repeated seeds of one prompt) reuses the graph,
-    new conditioning captures a new one (costs about one extra step)."""
+
+class _StaticTree:
+    """Device-resident copy of a conditioning tree (dicts / lists / tuples of tensors and plain values) with stable
+    addresses: a hipGraph captured on the copies serves every later clip of the same signature -- ``load`` copies a
+    new clip's tensors over the old ones.  Aliasing is part of the signature (the same tensor object in two places
+    stays one static tensor: the CFG halves share ``c_concat`` and the camera dict)."""
+
+    def __init__(self, tree):
+        self._memo = {}
+        self.slots = []           # static tensors in walk order
+        self._loaded = None       # (id, version) of the tensors last copied in, per slot
+        self.tree = self._build(tree)
+        self.signature = self.describe(tree)
+
+    # ---- structure ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _children(o):
+        """(kind, ordered children) of a container node, or None for a leaf."""
+        if isinstance(o, dict):
+            return "D", sorted(o.items(), key=lambda kv: str(kv[0]))
+        if isinstance(o, ops.MaskPack):
+            return "M", [(0, o[0]), (1, o[1]), ("wave_bits", o.wave_bits), ("group_order", o.group_order)]
+        if isinstance(o, (list, tuple)):
+            return ("L" if isinstance(o, list) else "U"), list(enumerate(o))
+        return None
+
+    @classmethod
+    def describe(cls, tree):
+        """Hashable signature: shapes, dtypes, aliasing pattern and the plain values."""
+        order = {}
+
+        def walk(o):
+            if torch.is_tensor(o):
+                n = order.setdefault(id(o), len(order))
+                return ("T", n, tuple(o.shape), str(o.dtype), str(o.device))
+            kids = cls._children(o)
+            if kids is None:
+                return ("V", repr(o))
+            return (kids[0],) + tuple((str(k), walk(v)) for k, v in kids[1])
+        return walk(tree)
+
+    def _build(self, o):
+        if torch.is_tensor(o):
+            hit = self._memo.get(id(o))
+            if hit is None:
+                hit = o.detach().clone(memory_format=torch.contiguous_format)
+                hit._ccv_static = True     # UNetModel's input cache then keys on the address, not on the version counter
+                self._memo[id(o)] = hit
+                self.slots.append(hit)
+            return hit
+        kids = self._children(o)
+        if kids is None:
+            return o
+        kind, items = kids
+        vals = [(k, self._build(v)) for k, v in items]
+        if kind == "D":
+            return {k: v for k, v in vals}
+        if kind == "M":
+            d = dict(vals)
+            return ops.MaskPack(d[0], d[1], d["wave_bits"], d["group_order"])
+        seq = [v for _, v in vals]
+        return seq if kind == "L" else tuple(seq)
+
+    # ---- per clip -------------------------------------------------------------------------------------------------
+    def load(self, tree):
+        """Copy the tensors of ``tree`` (same signature) into the static ones.  Returns True when anything changed."""
+        srcs, seen = [], set()
+
+        def walk(o):
+            if torch.is_tensor(o):
+                if id(o) not in seen:
+                    seen.add(id(o))
+                    srcs.append(o)
+                return
+            kids = self._children(o)
+            if kids is not None:
+                for _, v in kids[1]:
+                    walk(v)
+        walk(tree)
+        assert len(srcs) == len(self.slots)
+        stamp = [(id(t), t.data_ptr(), t._version) for t in srcs]
+        if stamp == self._loaded:
+            return False
+        for i, (dst, src) in enumerate(zip(self.slots, srcs)):
+            if self._loaded is None or self._loaded[i] != stamp[i]:
+                dst.copy_(src, non_blocking=True)
+        self._loaded = stamp
+        self._pinned = srcs       # keeps id() / data_ptr() of the sources meaningful until the next load
+        return True
+
+
+class _GraphedClip:
+    """One CFG DDIM step (batched UNet forward + fused guidance/update) captured into a hipGraph that serves every clip
+    of the same signature.
+
+    All conditioning tensors live in static copies (:class:`_StaticTree`).  Two graphs are captured on them:
+      * the *prologue* -- the step-invariant work of a clip (context K/V projections of all 16 cross-attention layers,
+        Pluecker feature rows, mask packing when bool masks were handed over): the UNet runs in ``inputs_only`` mode,
+        filling its input cache with tensors that live in the graph's pool, once per clip;
+      * the *step* -- the ~1.1k launches of a CFG step, replayed 25 times; only three tiny device copies (timestep
+        row, coefficient row, noise) precede each replay.
+    A new clip costs one copy of its conditioning (~0.1 GB) + one prologue replay; only a new *signature* (shapes,
+    kwargs, weights generation) captures again.  Graphs are cached on the model."""
 
     MAX_CACHED = 2
 
     @staticmethod
-    def _key(x, cond, stochastic, kw):
-        def ident(o):
-            if torch.is_tensor(o):
-                return ("T", id(o), o.data_ptr(), tuple(o.shape), o._version)
-            if isinstance(o, dict):
-                return tuple((k, ident(v)) for k, v in sorted(o.items(), key=lambda kv: str(kv[0])))
-            if isinstance(o, (list, tuple)):
-                return tuple(ident(v) for v in o)
-            return ("V", repr(o))
+    def _split(cond, kw):
         kw = dict(kw)
         uc = kw.get("unconditional_conditioning")
-        if isinstance(uc, dict):  # its camera entry is derived from `cond` inside the step (and added in place)
+        if (isinstance(uc, dict) and kw.get("enable_camera_condition") and isinstance(cond, dict)
+                and "camera_condition" in cond):
+            # its camera entry is derived from `cond` inside the step (p_sample_ddim writes it, like the reference)
             kw["unconditional_conditioning"] = {k: v for k, v in uc.items() if k != "camera_condition"}
-        return (tuple(x.shape), stochastic, ident(cond), ident(kw))
+        return {"cond": cond, "kw": kw}
 
     @classmethod
     def get(cls, sampler, x, cond, stochastic, kw):
         cache = sampler.model.__dict__.setdefault("_ccv_graph_cache", {})
-        key = cls._key(x, cond, stochastic, kw)
+        unet = _unet_of(sampler.model)
+        gen = getattr(unet, "weights_generation", 0)
+        for k in [k for k in cache if k[0] != gen]:      # graphs captured on weights that were since replaced
+            cache.pop(k)
+        tree = cls._split(cond, kw)
+        key = (gen, tuple(x.shape), stochastic, _StaticTree.describe(tree))
         hit = cache.get(key)
         if hit is None:
             while len(cache) >= cls.MAX_CACHED:
                 cache.pop(next(iter(cache)))
-            hit = cache[key] = cls(sampler, x, cond, stochastic, kw)
+            hit = cache[key] = cls(sampler, x, tree, stochastic)
         hit.sampler = sampler
+        hit.load(tree)
+        if isinstance(kw.get("unconditional_conditioning"), dict) and "camera_condition" in hit.static.tree["kw"]["unconditional_conditioning"]:
+            uc_cam = dict(cond["camera_condition"])      # what the eager path leaves in the caller's dict (ddim.py:259-260)
+            uc_cam["is_uc"] = True
+            kw["unconditional_conditioning"]["camera_condition"] = uc_cam
         return hit
 
-    def __init__(self, sampler, x, cond, stochastic, kw):
+    def __init__(self, sampler, x, tree, stochastic):
         dev = x.device
-        self.keepalive = (cond, kw)
+        self.static = _StaticTree(tree)
+        self.static.load(tree)
+        cond, kw = self.static.tree["cond"], self.static.tree["kw"]
         self.x = torch.empty_like(x)
         self.t = torch.zeros(x.shape[0], dtype=torch.long, device=dev)
         self.coef = torch.zeros(4, dtype=torch.float32, device=dev)
         self.noise = torch.zeros_like(x) if stochastic else None
         self.x.copy_(x)
         self.coef.copy_(sampler.ddim_coef[0])
+        unet = _unet_of(sampler.model)
 
         def step():
             return sampler.p_sample_ddim(self.x, cond, self.t, index=0, noise=self.noise, coef=self.coef, **kw)
 
-        # warm-up on a side stream: packs weights, fills the step-invariant caches, primes the allocator
+        # warm-up on a side stream: packs weights, primes the allocator
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             step()
         torch.cuda.current_stream().wait_stream(side)
+        self.prologue = None
+        if unet is not None and hasattr(unet, "inputs_only"):
+            unet.forget_inputs(self.static.slots)      # the warm-up's derived tensors live outside any graph pool
+            self.prologue = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.prologue):
+                with unet.inputs_only():
+                    step()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.x_prev, self.pred_x0 = step()
-        # the capture read the UNet's step-invariant caches (context K/V, masks, Plucker rows): pin those tensors
-        unet = getattr(getattr(sampler.model, "model", None), "diffusion_model", None)
-        cached = getattr(unet, "_inputs", None)
-        self.keepalive += (list(cached.items.values()) if cached is not None else [],)
+        # the captures baked in the addresses of the UNet's derived inputs and packed weights: pin both
+        self.keepalive = []
+        if unet is not None:
+            cached = getattr(unet, "_inputs", None)
+            self.keepalive.append(list(cached.items.values()) if cached is not None else [])
+            self.keepalive.append([m.__dict__.get("_pk_cache") for m in unet.modules()])
+        if self.prologue is not None:
+            self.prologue.replay()     # a capture does not execute: fill the derived inputs for the clip just loaded
+
+    def load(self, tree):
+        if self.static.load(tree) and self.prologue is not None:
+            self.prologue.replay()
 
     def run(self, x, t_row, coef_row, noise):
         if x.data_ptr() != self.x_prev.data_ptr():
@@ -227,7 +347,7 @@ class DDIMSampler(object):
         graphed = None
         if use_graph and not (callback or img_callback):
             stochastic = bool(np.any(self.ddim_sigmas != 0.0))
-            graphed = _GraphedStep.get(self, img, cond, stochastic, step_kw)
+            graphed = _GraphedClip.get(self, img, cond, stochastic, step_kw)
         for i in range(total):
             index = total - i - 1
             z = injected_noise[i].to(device).float().contiguous() if injected_noise is not None else None

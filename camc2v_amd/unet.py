@@ -617,7 +617,9 @@ class _InputCache:
 
     @staticmethod
     def key(tag, t):
-        return (tag, id(t), t.data_ptr(), tuple(t.shape), t._version)
+        # a tensor marked ``_ccv_static`` (the sampler's static conditioning copies) is refreshed in place together with
+        # everything derived from it (the captured prologue graph recomputes those): its version counter is not part of the key
+        return (tag, id(t), t.data_ptr(), tuple(t.shape), None if getattr(t, "_ccv_static", False) else t._version)
 
     def get(self, tag, t, make):
         k = self.key(tag, t)
@@ -630,6 +632,11 @@ class _InputCache:
         while len(self.items) > self.capacity:
             self.items.popitem(last=False)
         return val
+
+    def forget(self, tensors):
+        ids = {id(t) for t in tensors}
+        for k in [k for k, (t, _) in self.items.items() if id(t) in ids]:
+            del self.items[k]
 
     def clear(self):
         self.items.clear()
@@ -765,10 +772,31 @@ class UNetModel(nn.Module, _Prepared):
 
     # ---- packing ------------------------------------------------------------------------------------
     def invalidate_all(self):
+        """Drop every packed operand and derived input.  Runs on load_state_dict, .to() and enable_camera_conditioning;
+        IN-PLACE parameter edits (``p.data.copy_``, an EMA swap) are invisible to the module and must be followed by a
+        call to this method.  ``weights_generation`` lets holders of captured hipGraphs notice (camc2v_amd/sampler.py)."""
         for m in self.modules():
             if isinstance(m, _Prepared):
                 m.invalidate()
         self._inputs.clear()
+        self.__dict__["weights_generation"] = self.__dict__.get("weights_generation", 0) + 1
+
+    def forget_inputs(self, tensors):
+        """Drop the derived inputs (context K/V, Pluecker rows, packed masks) cached for the given input tensors."""
+        self._inputs.forget(tensors)
+
+    def inputs_only(self):
+        """Context manager: forwards compute the step-invariant inputs of their arguments (filling the input cache) and
+        return zeros.  The sampler captures this as the once-per-clip prologue graph."""
+        unet = self
+
+        class _Ctx:
+            def __enter__(self_):
+                unet.__dict__["_inputs_only"] = True
+
+            def __exit__(self_, *exc):
+                unet.__dict__["_inputs_only"] = False
+        return _Ctx()
 
     def _apply(self, fn, *args, **kwargs):  # .to()/.cuda() move parameters: packed copies become stale
         out = super()._apply(fn, *args, **kwargs)
@@ -884,6 +912,13 @@ class UNetModel(nn.Module, _Prepared):
         g = Geom(b0, t, H, W)          # geometry of the (possibly shared) prefix
         mc = self.model_channels
 
+        nclips, ctx_iter = self._context_groups(context, t)
+        if nclips != b:
+            raise CcvError(f"context covers {nclips} samples, x has {b}")
+        cam = self._camera_inputs(camera_condition, b, t, H, W)
+        if self.__dict__.get("_inputs_only"):
+            return torch.zeros((b, self.out_channels, t, H, W), dtype=torch.float32, device=x.device)
+
         # -- timestep / frame-stride embedding -> one fused projection for all ResBlocks ------------------
         def mlp(name, values):
             w0, b0, w2, b2 = pk[name]
@@ -893,16 +928,17 @@ class UNetModel(nn.Module, _Prepared):
         emb = mlp("time_embed", timesteps)
         emb_f = None
         if self.fs_condition:
+            nt = timesteps.shape[0]
             if fs is None:
-                fs = torch.full((b,), self.default_fs, dtype=torch.long, device=x.device)
+                fs = torch.full((nt,), self.default_fs, dtype=torch.long, device=x.device)
+            elif fs.numel() == 1 and nt > 1:
+                fs = fs.reshape(1).expand(nt)          # the reference broadcasts a single frame stride over the batch
+            elif fs.numel() != nt:
+                raise CcvError(f"fs has {fs.numel()} entries, timesteps has {nt}")
             emb_f = mlp("fps_embedding", fs)
         emb_all = ops.gemm(ops.add_silu_bf16(emb, emb_f), pk["w_emb"], bias=pk["b_emb"], out_f32=True)
         emb_state = [emb_all]          # run() reads the current one; replaced after the shared prefix
 
-        nclips, ctx_iter = self._context_groups(context, t)
-        if nclips != b:
-            raise CcvError(f"context covers {nclips} samples, x has {b}")
-        cam = self._camera_inputs(camera_condition, b, t, H, W)
         origin_h = None
         if cam is not None:
             origin_h = getattr(self, "epipolar_origin_h", 8 * H)

@@ -153,10 +153,17 @@ def _heads(t, h):
 def _attend(q, k, v, heads, mask=None):
     """softmax(q k^T / sqrt(d)) v, fp32.  q:[b,n,C] k,v:[b,m,C]; mask bool [b,n,m] (True = keep)."""
     qh, kh, vh = _heads(_r(q), heads), _heads(_r(k), heads), _heads(_r(v), heads)
-    sim = torch.einsum("bhid,bhjd->bhij", qh, kh) * (qh.shape[-1] ** -0.5)
-    if mask is not None:
-        sim = sim.masked_fill(~mask[:, None], float("-inf"))
-    out = torch.einsum("bhij,bhjd->bhid", _r(sim.softmax(-1)), vh)
+    n, m = qh.shape[2], kh.shape[2]
+    # softmax is per query row, so the scores may be formed a slab of queries at a time: the full-size epipolar
+    # attention (16384 x 16388 scores x 5 heads) would otherwise hold three 5.4 GB temporaries at once
+    rows = n if n * m * qh.shape[0] * heads <= (1 << 28) else max(64, (1 << 28) // (m * qh.shape[0] * heads))
+    outs = []
+    for i0 in range(0, n, rows):
+        sim = torch.einsum("bhid,bhjd->bhij", qh[:, :, i0:i0 + rows], kh) * (qh.shape[-1] ** -0.5)
+        if mask is not None:
+            sim = sim.masked_fill(~mask[:, None, i0:i0 + rows], float("-inf"))
+        outs.append(torch.einsum("bhij,bhjd->bhid", _r(sim.softmax(-1)), vh))
+    out = outs[0] if len(outs) == 1 else torch.cat(outs, 2)
     b, h, n, d = out.shape
     return out.permute(0, 2, 1, 3).reshape(b, n, h * d)
 

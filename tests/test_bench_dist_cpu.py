@@ -1,16 +1,19 @@
-"""The multi-process side of bench.py on CPU (gloo, world size 2): W untimed + K timed clips between barriers,
-MAX over ranks, whole-job frames/s.  The clip itself is a stand-in (the HIP path needs a GPU); what is checked
-is the launcher contract the driver relies on (clips shard across ranks, no data-path
-collective)."""
+"""The multi-process side of bench.py on CPU (gloo, world size 2): `bench.main()` itself is driven with a stand-in
+clip (the HIP path needs a GPU) -- W untimed + K timed clips between barriers, per-clip conditioning sets, the final
+all_gather of the latents, MAX over ranks, whole-job frames/s, one JSON line from rank 0 -- plus the launcher logic
+of `--gpus N` without a launcher (child process, never an exec).  What is checked is the contract the driver relies
+on (clips shard across ranks, no data-path collective inside the sampling loop)."""
+import contextlib
+import io
 import json
 import os
 import socket
+import subprocess
 import sys
 import time
 
 import pytest
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,43 +27,84 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     import bench
-    calls = {"n": 0}
+    calls = {"clips": [], "sets": 0}
 
-    def fake_clip():                       # rank 1 is the slow rank: the job time must be ITS time
-        calls["n"] += 1
-        time.sleep(0.05 * (1 + rank))
-        return torch.zeros(1)
+    def make_inputs(model, device, rank=0, clip=0):
+        calls["sets"] += 1
+        return (rank, clip)
 
-    elapsed, mine, _ = bench.timed_clips(fake_clip, steps=3, warmup=2, dist=dist)
-    line = bench.result_line(elapsed, 3, 2, world, use_graph=True) if rank == 0 else None
+    def fake_clip(model, r, clip, use_graph):       # rank 1 is the slow rank: the job time must be ITS time
+        calls["clips"].append(clip)
+        time.sleep(0.05 * (1 + r))
+        return torch.full((1, 4, 2, 2, 2), float(1 + r + 10 * clip))
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "2"],
+                        hooks=dict(device=torch.device("cpu"), backend="gloo", build_model=lambda dev: None,
+                                   synthetic_inputs=make_inputs, sample_clip=fake_clip))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
-        json.dump({"calls": calls["n"], "elapsed": elapsed, "mine": mine, "line": line}, f)
-    dist.barrier()
-    dist.destroy_process_group()
+        json.dump({"rc": rc, "clips": calls["clips"], "sets": calls["sets"], "stdout": buf.getvalue()}, f)
 
 
-def test_two_rank_timing_contract(tmp_path):
+def test_two_rank_bench_main(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(world)]
-    assert r[0]["calls"] == r[1]["calls"] == 5                      # 2 warm-up + exactly 3 timed
-    assert r[0]["elapsed"] == pytest.approx(r[1]["elapsed"])        # MAX over ranks is shared
-    assert r[0]["elapsed"] >= r[1]["mine"] - 1e-6 and r[1]["mine"] > r[0]["mine"] * 0.9
-    assert r[0]["elapsed"] >= 3 * 0.1 - 0.02
-    line = r[0]["line"]
+    assert r[0]["rc"] == 0 and r[1]["rc"] == 0
+    assert r[0]["clips"] == r[1]["clips"] == [0, 1, 2, 3, 4]        # 2 warm-up + exactly 3 timed, each its own input set
+    assert r[0]["sets"] == r[1]["sets"] == 5
+    assert r[1]["stdout"].strip() == ""                             # only rank 0 prints
+    lines = [ln for ln in r[0]["stdout"].splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 2 and line["scaling"] == "weak"
-    assert line["value"] == pytest.approx(16.0 * 3 * 2 / r[0]["elapsed"])    # whole-job frames/s
-    assert line["ms_per_step"] == pytest.approx(1e3 * r[0]["elapsed"] / 3)
+    # whole-job frames/s over the SLOWEST rank's time: rank 1 sleeps 0.1 s per clip
+    assert line["ms_per_step"] >= 100.0 - 5.0
+    assert line["value"] == pytest.approx(16.0 * 3 * 2 / (line["ms_per_step"] * 3 / 1e3))
+    assert line["config"]["ranks_in_final_all_gather"] == 2         # both ranks' latents arrived, and they differ
     assert line["roofline"]["bound"] == "mfma" and line["vs_baseline"] is None and line["dtype"] == "bf16"
     assert set(line) >= {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                          "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
+def test_gpus_flag_must_match_the_launcher(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"], hooks=dict(device=torch.device("cpu")))
+    assert "WORLD_SIZE=4" in str(e.value)
+
+
+def test_gpus_flag_without_launcher_spawns_a_child_job(monkeypatch):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the N-rank torch.distributed.run job is started as a child process
+    (subprocess.run, exit code relayed) before anything touches the GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched before the spawn")))
+    assert bench.main(["--gpus", "2", "--steps", "4", "--warmup", "1"]) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "4", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
 def test_bench_refuses_to_run_without_gpu():
-    import subprocess
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],

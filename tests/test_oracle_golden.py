@@ -297,3 +297,54 @@ def test_conditional_epipolar_mask_oracle_vs_reference_fixture(golden_dir):
     shape = tuple(int(v) for v in fx["cond_mask_shape"])
     ref = _unbits(fx["cond_mask"], shape[-1])
     assert torch.equal(geometry_oracle.epipolar_mask(torch.from_numpy(fx["cond_F"]), 8, 8, 8), ref)
+
+
+def test_oracle_sampler_follows_reference_25_step_trajectory(golden_dir):
+    """The oracle UNet + oracle sampler against the first three steps of the REFERENCE's 25-step trajectories
+    (tests/golden/traj_medium.npz, oracle/gen_golden_traj.py): camera + CFG 7.5 + rescale, and the plain CFG-off run."""
+    from oracle.golden_inputs import MEDIUM_CFG, medium_inputs
+    fx = np.load(os.path.join(golden_dir, "traj_medium.npz"))
+    med = np.load(os.path.join(golden_dir, "unet_medium.npz"))
+    man = json.load(open(os.path.join(golden_dir, "unet_medium_manifest.json")))
+    sd = unet_oracle.seeded_state_dict(man, SEED)
+    inp = medium_inputs()
+    F = torch.from_numpy(med["F128"])
+    masks = {d: geometry_oracle.epipolar_mask(F, 128 // d, 128 // d, d) for d in (8, 16, 32, 64)}
+    cam = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks, add_type="add_to_main_branch")
+    keep = [int(i) for i in fx["keep_steps"]]
+    assert keep[:3] == [0, 1, 2]
+
+    def eps(ctx, camera, state):
+        return lambda x, t: unet_oracle.unet_forward(state, MEDIUM_CFG, torch.cat([x, inp["c_concat"]], 1), t, ctx, inp["fs"],
+                                                     camera, origin_h=128)
+
+    class _Stop(Exception):
+        pass
+
+    def run(tag, seed_key, apply_c, apply_uc, scale, rescale):
+        torch.manual_seed(int(fx[seed_key]))
+        zs = [torch.randn(1, 4, 16, 16, 16) for _ in range(25)]
+        assert np.allclose([checksum(z) for z in zs], fx[f"{tag}_noise_checksum"], atol=1e-6)
+        seen = []
+
+        def counted(fn):
+            def wrapped(x, t):
+                if len(seen) == 3 and fn is apply_c:
+                    raise _Stop
+                if fn is apply_c:
+                    seen.append(x)
+                return fn(x, t)
+            return wrapped
+
+        try:
+            ddim_oracle.ddim_sample(counted(apply_c), counted(apply_uc) if apply_uc else None, inp["x_T"], 25, 1.0, scale, rescale, zs)
+        except _Stop:
+            pass
+        # seen[i] is the latent entering step i = the latent after step i-1
+        for i in (1, 2):
+            _close(seen[i], fx[f"{tag}_x_steps"][i - 1], 5e-4)
+
+    run("cam", "noise_seed_cam", eps(inp["ctx_rep"], cam, sd), eps(inp["ctx_pf"], cam, sd), 7.5, 0.7)
+    sd_plain = {k: v for k, v in sd.items() if ".pluker_projection." not in k and ".epipolar." not in k}
+    assert len(sd_plain) == int(fx["dc_num_keys"])
+    run("dc", "noise_seed_dc", eps(inp["ctx_pf"], None, sd_plain), None, 1.0, 0.0)

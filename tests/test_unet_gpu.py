@@ -328,3 +328,73 @@ def test_camera_guidance_trajectory(small):
     eager = _cfg_trajectory_vs_oracle(unet, sd, "model.camcontexti2v.CamContextI2V", **kw)
     graphed = _cfg_trajectory_vs_oracle(unet, sd, "model.camcontexti2v.CamContextI2V", use_graph=True, **kw)
     assert torch.equal(eager, graphed)
+
+
+def _small_core(unet):
+    from camc2v_amd.diffusion import LatentDiffusionCore
+    from oracle.golden_inputs import SMALL_CFG
+    core = LatentDiffusionCore({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": SMALL_CFG},
+                               linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4,
+                               image_size=[8, 8], temporal_length=16)
+    core.model.diffusion_model = unet
+    return core.to("cuda:0")
+
+
+def test_one_graph_serves_new_clips_and_notices_new_weights(small):
+    """The captured step graph lives on static copies of the conditioning: a clip with NEW tensors of the same shapes
+    replays the same graph (its step-invariant inputs are recomputed by the prologue graph), bit-identical to eager;
+    after load_state_dict the graph is captured again instead of replaying launches that read the old packed weights."""
+    unet, fx, sd, _, g, cam, _ = small
+    core = _small_core(unet)
+    core.__dict__.pop("_ccv_graph_cache", None)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    noises = [torch.randn(2, 4, 16, 8, 8, device="cuda", generator=gen) for _ in range(3)]
+
+    def clip(seed, use_graph):
+        gg = torch.Generator(device="cuda").manual_seed(seed)
+        rn = lambda like: torch.randn(like.shape, device="cuda", generator=gg)
+        cam2 = dict(cam, pluker_embedding_features=[rn(f) * 0.1 for f in cam["pluker_embedding_features"]])
+        cc = rn(g["c_concat"])
+        cond = dict(c_concat=[cc], c_crossattn=[rn(g["ctx_rep"])], camera_condition=cam2)
+        uncond = dict(c_concat=[cc], c_crossattn=[rn(g["ctx_pf"])])
+        s, _ = core.sample_log(cond, 2, True, 3, eta=1.0, x_T=rn(g["x"][:, :4]), unconditional_guidance_scale=7.5,
+                               unconditional_conditioning=uncond, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                               fs=g["fs"], enable_camera_condition=True, injected_noise=noises, use_graph=use_graph)
+        assert uncond["camera_condition"]["is_uc"] is True       # what the eager path (and the reference) leaves behind
+        return s.clone()
+
+    a_graph, b_graph = clip(1, True), clip(2, True)
+    assert len(core.__dict__["_ccv_graph_cache"]) == 1            # one capture served both clips
+    first = next(iter(core.__dict__["_ccv_graph_cache"].values()))
+    a_eager, b_eager = clip(1, False), clip(2, False)
+    assert torch.equal(a_graph, a_eager) and torch.equal(b_graph, b_eager)
+    assert not torch.equal(a_graph, b_graph)
+    # new weights: the old capture must not be replayed
+    sd2 = {k: (v * 1.01 if v.dim() > 1 else v) for k, v in sd.items()}
+    unet.load_state_dict(sd2, strict=True)
+    try:
+        c_graph = clip(1, True)
+        assert next(iter(core.__dict__["_ccv_graph_cache"].values())) is not first
+        assert torch.equal(c_graph, clip(1, False))
+        assert not torch.equal(c_graph, a_graph)
+    finally:
+        unet.load_state_dict(sd, strict=True)
+        core.__dict__.pop("_ccv_graph_cache", None)
+
+
+def test_cfg_pair_falls_back_when_halves_do_not_share_the_camera(small):
+    """A conditional dict with a camera but enable_camera_condition off: the reference's second apply_model runs WITHOUT
+    the camera (ddim.py:258-263).  The batched 2b forward cannot express that, so apply_model_pair must take two forwards."""
+    unet, _, _, _, g, cam, _ = small
+    core = _small_core(unet)
+    cond = dict(c_concat=[g["c_concat"]], c_crossattn=[g["ctx_rep"]], camera_condition=cam)
+    uncond = dict(c_concat=[g["c_concat"]], c_crossattn=[g["ctx_pf"]])
+    x = g["x"][:, :4].contiguous()
+    e_c, e_uc = core.apply_model_pair(x, g["t"], cond, uncond, fs=g["fs"])
+    want_uc = core.apply_model(x, g["t"], uncond, fs=g["fs"])                     # no camera
+    with_cam = core.apply_model(x, g["t"], dict(uncond, camera_condition=cam), fs=g["fs"])
+    assert torch.equal(e_uc, want_uc) and not torch.equal(e_uc, with_cam)
+    assert torch.equal(e_c, core.apply_model(x, g["t"], cond, fs=g["fs"]))
+    # the sampler's shared copy (same tensors + the is_uc marker) does take the batched path
+    shared = dict(uncond, camera_condition=dict(cam, is_uc=True))
+    assert core._same_extras(cond, shared) and not core._same_extras(cond, uncond)
