@@ -603,16 +603,23 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 // Work distribution: a 64-query group costs between ~0.5x and ~1.4x the average (its bitmap popcount), and the
 // 2560 groups of the 32x32-latent layers do not divide over the 2048 resident waves, so a static grid ends with
 // half-empty CUs waiting for the last workgroups (measured: 47 % average wave occupancy).  The kernel is therefore
-// persistent: every wave pulls the next item from a counter, and the items are ordered longest first
-// (p.group_order, built with the mask): item i = (rank i / BH, batch-head i % BH).  In a simulation of the
-// benchmark mask this brings the makespan from 1.79x to 1.34x the ideal (total work / resident waves).
-__device__ unsigned int g_sparse_ctr[64];
+// persistent: every wave pulls its next item from a counter, and items are ordered longest first (p.group_order,
+// built with the mask).
+// XCD-local queues: an item is (batch-head slice, rank).  One slice's K and V are 4 MiB at 32x32 latents -- a whole
+// XCD L2 -- and a launch has 10 (32x32) or 20 (16x16) slices; dealing items round-robin over the slices made every
+// XCD stream ALL slices through its 4 MiB L2 (measured 1.5 GB fetched per launch against 80 MB of operands).  Each XCD
+// therefore has a queue of its own (one counter per XCD): its "home" slices (slice % 8 == XCD) in full, plus an equal
+// share of one of the nbh % 8 leftover slices (the ranks r with r % c == q, c = XCDs sharing that slice), merged in
+// rank order so the queue is still longest-first.  A wave reads its XCD from HW_REG_XCC_ID, drains that queue and
+// then helps the other XCDs' queues (x+1, x+2, ...), so any placement of workgroups finishes all the work; the
+// placement only decides how local the K/V traffic is.
+__device__ unsigned int g_sparse_ctr[64][8];
 
 __global__ void sparse_ctr_reset(int slot) {
-    if (threadIdx.x == 0) g_sparse_ctr[slot] = 0u;
+    if (threadIdx.x < 8) g_sparse_ctr[slot][threadIdx.x] = 0u;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, int slot) {
+__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, int slot, int use_xcd_queues) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words
     unsigned char* smw = sm + 4 * 2 * 8192;
     const int tid = threadIdx.x;
@@ -625,16 +632,24 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
     constexpr int DONE = 0x7fffffff;
     const bool has_reg = p.kreg != nullptr && p.nreg > 0;
     const int ngroups = (p.Lq + 63) >> 6;
-    const long total = (long)p.B * p.H * ngroups;
     const int nbh = p.B * p.H;
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc = (use_xcd_queues == 2) ? (int)(blockIdx.x & 7) : (xcc & 7);   // 2 (A/B aid): the round-robin dispatch label instead
 
+  for (int qstep = 0; qstep < (use_xcd_queues ? 8 : 1); ++qstep) {
+    const int xq = use_xcd_queues ? (xcc + qstep) & 7 : 0;      // own queue first, then the others'
+    // use_xcd_queues == 0 (A/B aid): one queue for the whole chip, slices dealt round-robin (item = rank * nbh + slice)
+    const long qitems = use_xcd_queues ? ccv_sparse_queue_items(nbh, ngroups, xq) : (long)nbh * ngroups;
   for (;;) {
     unsigned int idx = 0;
-    if (lane == 0) idx = atomicAdd(&g_sparse_ctr[slot], 1u);
+    if (lane == 0) idx = atomicAdd(&g_sparse_ctr[slot][xq], 1u);
     const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
-    if (item >= total) break;
-    const int rank = (int)(item / nbh);
-    const int bh = (int)(item % nbh);
+    if (item >= qitems) break;
+    int bh, rank;
+    if (use_xcd_queues) ccv_sparse_queue_item(nbh, ngroups, xq, item, bh, rank);
+    else { rank = (int)(item / nbh); bh = (int)(item % nbh); }
+    if (rank >= ngroups) continue;
     const int head = bh % p.H, b = bh / p.H;
     const int qg = p.group_order ? p.group_order[(long)(b % p.mask_nb) * p.order_bs + rank] : rank;
     const long bo = b / p.inner, bi = b % p.inner;
@@ -832,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         }
     }
   }  // next query group
+  }  // next queue
 }
 
 // =================================================================================================
@@ -918,6 +934,19 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
 
 }  // namespace
 
+// Host-side view of the sparse kernel's work queues (tests): item `idx` of XCD `xq`'s queue -> (slice, rank); returns the
+// queue length (rank >= ngroups marks a padding item the kernel skips).
+extern "C" int64_t ccv_attn_sparse_queue_item(int32_t nbh, int32_t ngroups, int32_t xq, int64_t idx, int32_t* bh, int32_t* rank) {
+    const long n = ccv_sparse_queue_items(nbh, ngroups, xq);
+    if (bh && rank && idx >= 0 && idx < n) {
+        int b_, r_;
+        ccv_sparse_queue_item(nbh, ngroups, xq, idx, b_, r_);
+        *bh = b_;
+        *rank = r_;
+    }
+    return n;
+}
+
 static bool two_ctx_on() {   // CCV_ATTN_TWO=0: two-context calls on the first-generation kernel (A/B aid)
     static const bool v = [] { const char* e = getenv("CCV_ATTN_TWO"); return !(e && e[0] == '0'); }();
     return v;
@@ -988,7 +1017,10 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             const long groups = (long)((p.Lq + 63) / 64) * p.H * p.B;
             const long wgs = (groups + 3) / 4 < 2l * n_cu ? (groups + 3) / 4 : 2l * n_cu;
             hipLaunchKernelGGL(sparse_ctr_reset, dim3(1), dim3(64), 0, st, slot);
-            hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, p, slot);
+            static const int xcd_queues = [] { const char* e = getenv("CCV_ATTN_XCD"); return e ? atoi(e) : 0; }();   // 0 (default): one chip-wide queue; 1: per-XCD queues
+            // (HW_REG_XCC_ID); 2: per-XCD queues with blockIdx & 7 as the label.  Measured on MI355X (profiles/r02_sparse_xcd_queues.txt):
+            // the XCD-local queues are SLOWER (32x32 latents 585 -> 621 us, 16x16 168 -> 208 us per b=2 launch), so they stay off
+            hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, p, slot, xcd_queues);
         }
         else if (p.mask_bits)
             hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);

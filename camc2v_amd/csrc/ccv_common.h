@@ -66,6 +66,45 @@ __host__ __device__ __forceinline__ int ccv_patch_row(int idx, int hw, int w) {
     return f * hw + (py * 4 + (within >> 3)) * w + px * 8 + (within & 7);
 }
 
+// ---- work queues of the sparse attention kernel (ccv_attn.hip): XCD `xq` owns the slices s with s % 8 == xq ("home",
+// n_full = nbh / 8 of them) in full and, of the n_extra = nbh % 8 leftover slices, the ranks r with r % c == q of slice
+// 8 n_full + k, where k = xq % n_extra, c = number of XCDs with that k and q = xq / n_extra.  Items are merged in rank
+// order (rank = position in the longest-first order): per block of c ranks, the home items of each rank and, after rank
+// r0 + q, the one leftover item.  Every (slice, rank) pair appears in exactly one queue.
+__host__ __device__ __forceinline__ void ccv_sparse_queue_geom(int nbh, int xq, int& n_full, int& k, int& c, int& q) {
+    n_full = nbh >> 3;
+    const int n_extra = nbh & 7;
+    k = 0; c = 1; q = 0;
+    if (n_extra > 0) {
+        k = xq % n_extra;
+        c = (7 - k) / n_extra + 1;
+        q = xq / n_extra;
+    }
+}
+__host__ __device__ __forceinline__ long ccv_sparse_queue_items(int nbh, int ngroups, int xq) {
+    int n_full, k, c, q;
+    ccv_sparse_queue_geom(nbh, xq, n_full, k, c, q);
+    const int per_blk = c * n_full + ((nbh & 7) ? 1 : 0);
+    return (long)((ngroups + c - 1) / c) * per_blk;
+}
+__host__ __device__ __forceinline__ void ccv_sparse_queue_item(int nbh, int ngroups, int xq, long idx, int& bh, int& rank) {
+    int n_full, k, c, q;
+    ccv_sparse_queue_geom(nbh, xq, n_full, k, c, q);
+    (void)ngroups;
+    const bool extra = (nbh & 7) != 0;
+    const int per_blk = c * n_full + (extra ? 1 : 0);
+    const int blk = (int)(idx / per_blk);
+    int rem = (int)(idx - (long)blk * per_blk);
+    const int r0 = blk * c;
+    if (extra) {
+        const int ext_pos = (q + 1) * n_full;
+        if (rem == ext_pos) { bh = 8 * n_full + k; rank = r0 + q; return; }
+        if (rem > ext_pos) --rem;
+    }
+    rank = r0 + rem / n_full;
+    bh = xq + 8 * (rem % n_full);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

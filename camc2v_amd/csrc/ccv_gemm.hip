@@ -173,10 +173,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
             a_base[i] = (m < p.M) ? img * p.src_h * p.src_w : -1;
             a_y[i] = oy * p.stride - (p.no_lead_pad ? 0 : 1);
             a_x[i] = ox * p.stride - (p.no_lead_pad ? 0 : 1);
-        } else {
+        } else if (GATHER == 2) {
             a_base[i] = (m < p.M) ? m : -1;
             a_y[i] = (m / p.hw) % p.frames;  // frame index within the clip
             a_x[i] = 0;
+        } else {
+            a_base[i] = (m < p.M) ? m : -1;
+            a_y[i] = a_x[i] = 0;
         }
     }
     const int slabs_per_tap = p.K / BKT;
@@ -205,9 +208,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
                     const int vh = p.src_h << p.upsample, vw = p.src_w << p.upsample;
                     if (iy >= 0 && iy < vh && ix >= 0 && ix < vw)
                         src = a_base[i] + (iy >> p.upsample) * p.src_w + (ix >> p.upsample);
-                } else {
+                } else if (GATHER == 2) {
                     const int f = a_y[i] + tap - 1;
                     if (f >= 0 && f < p.frames) src = (long)a_base[i] + (long)(tap - 1) * p.hw;
+                } else {
+                    src = (long)a_base[i] + (long)tap * p.hw;   // segment `tap` of the stacked operand
                 }
             }
             if (A_F32) {
@@ -393,10 +398,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
             a_base[j] = (m < p.M) ? img * p.src_h * p.src_w : -1;
             a_y[j] = oy * p.stride - (p.no_lead_pad ? 0 : 1);
             a_x[j] = ox * p.stride - (p.no_lead_pad ? 0 : 1);
-        } else {
+        } else if (GATHER == 2) {
             a_base[j] = (m < p.M) ? m : -1;
             a_y[j] = (m / p.hw) % p.frames;
             a_x[j] = 0;
+        } else {
+            a_base[j] = (m < p.M) ? m : -1;
+            a_y[j] = a_x[j] = 0;
         }
     }
     const int ldw = p.taps * p.K;
@@ -434,9 +442,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
                     const int vh = p.src_h << p.upsample, vw = p.src_w << p.upsample;
                     if (iy >= 0 && iy < vh && ix >= 0 && ix < vw)
                         src = a_base[j] + (iy >> p.upsample) * p.src_w + (ix >> p.upsample);
-                } else {
+                } else if (GATHER == 2) {
                     const int f = a_y[j] + tap - 1;
                     if (f >= 0 && f < p.frames) src = (long)a_base[j] + (long)(tap - 1) * p.hw;
+                } else {
+                    src = (long)a_base[j] + (long)tap * p.hw;   // segment `tap` of the stacked operand
                 }
             }
             a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
@@ -638,10 +648,13 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             a_base[j] = (m < p.M) ? img * p.src_h * p.src_w : -1;
             a_y[j] = oy * p.stride - (p.no_lead_pad ? 0 : 1);
             a_x[j] = ox * p.stride - (p.no_lead_pad ? 0 : 1);
-        } else {
+        } else if (GATHER == 2) {
             a_base[j] = (m < p.M) ? m : -1;
             a_y[j] = (m / p.hw) % p.frames;
             a_x[j] = 0;
+        } else {
+            a_base[j] = (m < p.M) ? m : -1;
+            a_y[j] = a_x[j] = 0;
         }
     }
     const int ldw = p.taps * p.K;
@@ -674,9 +687,11 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
                     const int vh = p.src_h << p.upsample, vw = p.src_w << p.upsample;
                     if (iy >= 0 && iy < vh && ix >= 0 && ix < vw)
                         src = a_base[j] + (iy >> p.upsample) * p.src_w + (ix >> p.upsample);
-                } else {
+                } else if (GATHER == 2) {
                     const int f = a_y[j] + tap - 1;
                     if (f >= 0 && f < p.frames) src = (long)a_base[j] + (long)(tap - 1) * p.hw;
+                } else {
+                    src = (long)a_base[j] + (long)tap * p.hw;   // segment `tap` of the stacked operand
                 }
             }
             a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
@@ -1150,6 +1165,13 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
             CCV_REQUIRE(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0, CCV_EINVAL, "ccv_gemm: bad tconv geometry");
             CCV_REQUIRE(!p.a_f32, CCV_ESHAPE, "ccv_gemm: tconv3 takes bf16 activations");
             return dispatch_tile<false, 2>(p, ring, st);
+        case 3:
+            // stacked operand: A = [taps][hw rows][lda], out[m] = sum_t A[t][m] . W[:, t*K:(t+1)*K]^T -- several linear maps
+            // into the same output (e.g. the three projections a camera-conditioned temporal block adds to its stream,
+            // modified_forwards.py:519-529) as ONE GEMM with one epilogue
+            CCV_REQUIRE(p.taps >= 1 && p.hw >= p.M, CCV_EINVAL, "ccv_gemm: segment gather needs taps >= 1 and a segment stride (hw) >= M");
+            CCV_REQUIRE(!p.a_f32, CCV_ESHAPE, "ccv_gemm: segment gather takes bf16 activations");
+            return dispatch_tile<false, 3>(p, ring, st);
         default:
             ccv_set_error("ccv_gemm: unknown gather %d", p.gather);
             return CCV_EINVAL;

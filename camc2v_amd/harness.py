@@ -1,0 +1,111 @@
+"""Generation harness: the eval_config.yaml that 02_generate_videos.py writes -> per-sample output directories, without
+PyTorch-Lightning (reference flow: CamContextI2V/02_generate_videos.py:197-355 -> main/trainer.py:80,146-194 -> ImageLogger
+(main/callbacks.py:163-196, 238-245) -> model.log_images -> utils/save_video.py:65-157).
+
+    python generate.py <eval_config.yaml> [--out DIR] [--num-samples N] [--synthetic-data] [--random-init] [--no-graph]
+
+What is honoured from the yaml: ``model`` (target / params / pretrained_checkpoint), ``data.params.{batch_size, test,
+test_max_n_samples}``, ``lightning.callbacks.batch_logger.params.{log_images_kwargs, test_directory}``.  One process per GPU
+(RANK / WORLD_SIZE from torchrun): the test set is sharded over ranks like Lightning's DistributedSampler does and every rank
+writes its own samples (``log_all_gpus: True`` in the reference's eval config); no collective is needed.
+"""
+import argparse
+import logging
+import os
+import time
+
+import torch
+import yaml
+
+from .checkpoint import load_checkpoints
+from .config import instantiate_from_config
+from .data import SyntheticRealEstate, collate
+from .video_io import log_evaluation, prepare_to_log
+
+log = logging.getLogger("mainlogger")
+
+
+def build_model(cfg, device, random_init=False, report=None):
+    model = instantiate_from_config(cfg["model"])
+    model.build_feeders()
+    ckpt = cfg["model"].get("pretrained_checkpoint")
+    if ckpt and os.path.exists(ckpt):
+        load_checkpoints(model, cfg["model"], report)
+        return model.to(device).eval()
+    if not random_init:
+        raise FileNotFoundError(f"pretrained_checkpoint {ckpt!r} not found (pass --random-init to sample from seeded random weights)")
+    log.warning("no checkpoint at %r: seeded random weights (smoke / benchmark mode)", ckpt)
+    model = model.to(device)
+    g = torch.Generator(device=device).manual_seed(20230211)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.normal_(0.0, 0.02, generator=g)
+            if p.dim() == 1 and name.endswith(".weight"):
+                p.add_(1.0)
+    unet = model.model.diffusion_model
+    if hasattr(unet, "invalidate_all"):
+        unet.invalidate_all()          # in-place parameter edits are invisible to the packed-operand caches
+    for m in model.modules():
+        if hasattr(m, "invalidate") and m is not unet:
+            m.invalidate()
+    return model.eval()
+
+
+def build_dataset(cfg, synthetic=False, num_samples=None):
+    dcfg = cfg.get("data", {}).get("params", {})
+    test = dcfg.get("test") or dcfg.get("validation") or {}
+    params = dict(test.get("params", {}))
+    n = num_samples if num_samples is not None else dcfg.get("test_max_n_samples") or dcfg.get("validation_max_n_samples") or 4
+    ds = None
+    if not synthetic and test.get("target") and os.path.isdir(str(params.get("data_dir", ""))):
+        try:
+            ds = instantiate_from_config(test)
+        except Exception as e:      # the reference's dataset class needs decord + the RealEstate10K files
+            log.warning("could not build %s (%s): falling back to synthetic clips", test.get("target"), e)
+    if ds is None:
+        ds = SyntheticRealEstate(num_samples=n, **{k: v for k, v in params.items()
+                                                    if k in ("video_length", "resolution", "frame_stride", "num_additional_cond_frames",
+                                                             "exclude_samples")})
+    return ds, int(dcfg.get("batch_size", 1)), int(n)
+
+
+def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None):
+    """Returns the list of sample directories written by this rank."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if device is None:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.set_grad_enabled(False)
+    model = build_model(cfg, device, random_init)
+    ds, batch_size, n = build_dataset(cfg, synthetic, num_samples)
+    logger = cfg.get("lightning", {}).get("callbacks", {}).get("batch_logger", {}).get("params", {})
+    kw = dict(logger.get("log_images_kwargs") or {})
+    save_dir = out_dir or logger.get("test_directory") or os.path.join("results", "test")
+    os.makedirs(save_dir, exist_ok=True)
+    idx = list(range(min(n, len(ds))))[rank::world]
+    written, t0 = [], time.perf_counter()
+    for s in range(0, len(idx), batch_size):
+        batch = collate([ds[i] for i in idx[s:s + batch_size]])
+        logs = model.log_images(batch, split="test", use_graph=use_graph, **kw)
+        logs = prepare_to_log(logs, -1, True)
+        written += log_evaluation(logs, save_dir, save_fps=7, rescale=True, print_out=(rank == 0))
+    dt = time.perf_counter() - t0
+    log.info("[rank %d] %d clips in %.1f s -> %s", rank, len(written), dt, save_dir)
+    return written
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\\n")[0])
+    ap.add_argument("config", help="eval_config.yaml written by 02_generate_videos.py (or any config with a `model:` section)")
+    ap.add_argument("--out", default=None, help="output directory (default: batch_logger.test_directory)")
+    ap.add_argument("--num-samples", type=int, default=None)
+    ap.add_argument("--synthetic-data", action="store_true", help="iterate synthetic clips even if the dataset directory exists")
+    ap.add_argument("--random-init", action="store_true", help="sample from seeded random weights when the checkpoint is absent")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s")
+    with open(args.config) as f:
+        cfg = yaml.safe_load(f)
+    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph)
+    print(f"wrote {len(written)} sample directories")
+    return 0

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ccv_pack_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ccv_epipolar_mask_bits": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ccv_attn_group_order": (i32, [vp, i32, i32, i32, vp, vp]),
+    "ccv_attn_sparse_queue_item": (i64, [i32, i32, i32, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 _lib = None

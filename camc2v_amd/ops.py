@@ -14,7 +14,7 @@ from .lib import CcvAttn, CcvError, CcvGemm, check, lib
 BF16 = torch.bfloat16
 F32 = torch.float32
 
-GATHER_LINEAR, GATHER_CONV3X3, GATHER_TCONV3 = 0, 1, 2
+GATHER_LINEAR, GATHER_CONV3X3, GATHER_TCONV3, GATHER_SEGMENTS = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 
 # 0: V^T fragments through ds_read_b64_tr_b16; 1: V transposed while staging (fallback)
@@ -47,11 +47,12 @@ def _rows(t):
 # ---------------------------------------------------------------------------------------
 def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
          residual=None, act=ACT_NONE, geglu=False, out_f32=False, out=None, gather=GATHER_LINEAR,
-         conv=None, tconv=None, alpha=1.0):
+         conv=None, tconv=None, seg_rows=None, alpha=1.0):
     """out[m, n] = epilogue(sum_tap gather(a) @ w_tap^T).  See include/ccv.h (ccv_gemm).
 
     a: [rows, lda] bf16 or fp32 (2-D, last dim contiguous); w: [N, taps*K] bf16.
-    conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw).
+    conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw);
+    seg_rows (GATHER_SEGMENTS): a = `taps` stacked operands, `seg_rows` rows apart; tap t multiplies rows [t*seg_rows, +M).
     """
     _dev(a, w, bias, bias2, residual, out)
     if a.dim() != 2 or a.stride(1) != 1:
@@ -101,6 +102,10 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         if pix <= 0 or M % pix or a.shape[0] < (M // pix) * p.src_h * p.src_w:
             raise CcvError(f"gemm: conv3x3 output rows M={M} = images x {p.out_h}x{p.out_w} need {(M // max(pix, 1)) * p.src_h * p.src_w} "
                            f"source rows ({p.src_h}x{p.src_w} per image), A has {a.shape[0]} (pass m= for strided / upsampling convolutions)")
+    elif gather == GATHER_SEGMENTS:
+        if seg_rows is None or seg_rows < M or a.shape[0] < (taps - 1) * seg_rows + M or a.dtype != BF16:
+            raise CcvError(f"gemm: segment gather needs bf16 A with {taps} segments of >= M = {M} rows, seg_rows = {seg_rows}, A has {a.shape[0]} rows")
+        p.hw = seg_rows
     else:
         if a.shape[0] < M:
             raise CcvError(f"gemm: A has {a.shape[0]} rows, M = {M}")
@@ -212,8 +217,8 @@ def groupnorm(x, gamma, beta, *, instances, eps, silu):
     return y
 
 
-def layernorm(x, gamma, beta, *, eps=1e-5, addend=None):
-    """x [rows, C] fp32 -> bf16 (and y + addend[r % addend_rows] when addend is given)."""
+def layernorm(x, gamma, beta, *, eps=1e-5, addend=None, out2=None):
+    """x [rows, C] fp32 -> bf16 (and y + addend[r % addend_rows] when addend is given; `out2`: where that second output goes)."""
     _dev(x, gamma, beta, addend)
     if x.dtype != F32:
         raise CcvError("layernorm: x must be fp32 (the residual stream)")
@@ -225,7 +230,9 @@ def layernorm(x, gamma, beta, *, eps=1e-5, addend=None):
         if addend.dtype != BF16 or not addend.is_contiguous() or addend.shape[-1] != Cc:
             raise CcvError("layernorm: addend must be contiguous bf16 [rows', C]")
         arows = addend.numel() // Cc
-        y2 = torch.empty_like(y)
+        y2 = torch.empty_like(y) if out2 is None else out2
+        if y2.dtype != BF16 or not y2.is_contiguous() or tuple(y2.shape) != tuple(y.shape):
+            raise CcvError("layernorm: out2 must be contiguous bf16 shaped like the output")
     check(lib().ccv_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _ptr(addend), arows,
                               _ptr(y2), _stream()), "ccv_layernorm")
     return (y, y2) if addend is not None else y

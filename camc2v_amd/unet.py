@@ -29,6 +29,8 @@ from . import ops, pack
 from .lib import CcvError
 
 Geom = namedtuple("Geom", "b t h w")
+# A/B aid: CCV_FUSE_CAM=0 runs the three stream updates of a camera-conditioned temporal block as three GEMMs
+FUSE_CAMERA_PROJECTIONS = __import__("os").environ.get("CCV_FUSE_CAM", "1") != "0"
 TEXT_LEN = 77  # CrossAttention.text_context_len (reference attention.py:49)
 
 
@@ -126,16 +128,21 @@ class CrossAttention(nn.Module, _Prepared):
         ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
 
     # ---- self attention over the frames of each pixel; activations stay token-major -------------
-    def self_attn_temporal(self, n, stream, g):
+    def temporal_attend(self, n, g, out=None):
+        """softmax(q k^T) v over the frames of each pixel, before the output projection: bf16 [(b t hw), C] (into `out`)."""
         pk = self._pk()
         C, H, hw = self.query_dim, self.heads, g.h * g.w
         qkv = ops.gemm(n, pk["w_qkv"])
         ld = 3 * C
         s = (g.t * hw * ld, ld, hw * ld)
-        o = torch.empty((n.shape[0], C), dtype=ops.BF16, device=n.device)
+        o = torch.empty((n.shape[0], C), dtype=ops.BF16, device=n.device) if out is None else out
         ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b * hw, inner=hw, H=H, Lq=g.t, Lk=g.t,
                       q_str=s, k_str=s, v_str=s, out=o, o_str=(g.t * hw * C, C, hw * C), scale=self.scale)
-        ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+        return o
+
+    def self_attn_temporal(self, n, stream, g):
+        pk = self._pk()
+        ops.gemm(self.temporal_attend(n, g), pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
 
     # ---- cross attention against cached context projections --------------------------------------
     def project_context(self, text_rows, img_rows):
@@ -286,6 +293,11 @@ class Epipolar(nn.Module, _Prepared):
     def run(self, src, stream, g, packed_mask):
         """src [(b t hw), C] bf16 (= LN(x) + Pluecker rows); packed_mask (bits, flags, nb) or None."""
         pk = self._pk()
+        ops.gemm(self.attend(src, g, packed_mask), pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+
+    def attend(self, src, g, packed_mask, out=None):
+        """The masked attention over all T*H*W tokens, before the output projection: bf16 [(b t hw), C] (into `out`)."""
+        pk = self._pk()
         C, H = self.query_dim, self.num_heads
         L = g.t * g.h * g.w
         qkv = ops.gemm(src, pk["w_qkv"])
@@ -299,9 +311,10 @@ class Epipolar(nn.Module, _Prepared):
             if perm is not None and perm != (g.h * g.w, g.w):
                 raise CcvError(f"epipolar mask was packed for frames {perm}, feature map is {g.h}x{g.w}")
             kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm, wave_bits=wbits, group_order=order)
-        o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
-                          kreg=pk.get("kreg"), vreg=pk.get("vreg"), scale=self.epipolar_attn.scale, **kw)
-        ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+        if out is not None:
+            kw.update(out=out, o_str=(L * C, 0, C))
+        return ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,
+                             kreg=pk.get("kreg"), vreg=pk.get("vreg"), scale=self.epipolar_attn.scale, **kw)
 
 
 class BasicTransformerBlock(nn.Module, _Prepared):
@@ -338,11 +351,18 @@ class BasicTransformerBlock(nn.Module, _Prepared):
         if hasattr(self, "pluker_projection"):
             pk["w_pl"] = pack.pack_linear(self.pluker_projection.weight)
             pk["b_pl"] = _dev_f32(self.pluker_projection.bias)
+            if hasattr(self, "epipolar") and self.epipolar.epipolar_attn.dim_head == 64:
+                # 'add_to_main_branch': x += attn1.to_out(o1) + pluker_projection(n + P) + epipolar.to_out(o2) -- three linear maps
+                # into the stream: ONE GEMM over the stacked operands [o1; n + P; o2] against [W_o1 | W_pl | W_oe]
+                # (K = 3C, one read-modify-write of the fp32 stream instead of three)
+                wo1, woe = self.attn1.to_out[0], self.epipolar.epipolar_attn.to_out[0]
+                pk["w_cam"] = pack.pack_linear(torch.cat([wo1.weight, self.pluker_projection.weight, woe.weight], 1))
+                pk["b_cam"] = _dev_f32(wo1.bias.float() + self.pluker_projection.bias.float() + woe.bias.float())
         return pk
 
-    def _ln(self, i, stream, addend=None):
+    def _ln(self, i, stream, addend=None, out2=None):
         pk = self._pk()
-        return ops.layernorm(stream, pk[f"g{i}"], pk[f"b{i}"], eps=getattr(self, f"norm{i}").eps, addend=addend)
+        return ops.layernorm(stream, pk[f"g{i}"], pk[f"b{i}"], eps=getattr(self, f"norm{i}").eps, addend=addend, out2=out2)
 
     def run_spatial(self, stream, g, ctx_groups, final=False):
         self.attn1.self_attn_spatial(self._ln(1, stream), stream, g)
@@ -357,11 +377,21 @@ class BasicTransformerBlock(nn.Module, _Prepared):
         else:
             pk = self._pk()
             prow = cam.get("rows")
+            main = cam.get("add_type") == "add_to_main_branch"
+            if main and prow is not None and "w_cam" in pk and FUSE_CAMERA_PROJECTIONS:
+                rows, C = stream.shape
+                stack = torch.empty((3, rows, C), dtype=ops.BF16, device=stream.device)   # [o1 ; n + P ; o2]
+                n, _ = self._ln(1, stream, addend=prow, out2=stack[1])
+                self.attn1.temporal_attend(n, g, out=stack[0])
+                self.epipolar.attend(stack[1], g, cam.get("mask"), out=stack[2])
+                ops.gemm(stack.view(3 * rows, C), pk["w_cam"], k=C, taps=3, m=rows, gather=ops.GATHER_SEGMENTS, seg_rows=rows,
+                         bias=pk["b_cam"], residual=stream, out_f32=True, out=stream)
+                self.attn2.self_attn_temporal(self._ln(2, stream), stream, g)
+                return self.ff.run(self._ln(3, stream), stream, final)
             if prow is not None:
                 n, src = self._ln(1, stream, addend=prow)
             else:
                 n = src = self._ln(1, stream)
-            main = cam.get("add_type") == "add_to_main_branch"
             target = stream if main else torch.zeros_like(stream)
             if main:
                 self.attn1.self_attn_temporal(n, stream, g)

@@ -59,6 +59,11 @@ const char* ccv_last_error(void);
  *                             with `upsample` the source image (src_h x src_w) is first
  *                             nearest-upsampled 2x (F.interpolate, openaimodel3d.py:103)
  *        gather 2 (tconv3)  : m = (clip, frame, pixel); tap kt reads frame+kt-1, zero outside
+ *        gather 3 (segments): A is `taps` stacked operands [taps][hw rows][lda]; tap t reads row m of segment t.
+ *                             Several linear maps into the same output run as ONE GEMM over K' = taps*K with one
+ *                             epilogue: x += attn1.to_out(o1) + pluker_projection(n + P) + epipolar.to_out(o2) of a
+ *                             camera-conditioned temporal block (model/modules/modified_forwards.py:519-529) reads and
+ *                             writes the fp32 stream once instead of three times.
  * W  : [N, taps*K] bf16 row-major, k index = tap*K + c  (prepared once from the checkpoint)
  * out: v = alpha*acc + bias[n] + bias2[(m / rows_per_batch)*ldb2 + n]; v = act(v);
  *      geglu: W rows are interleaved in 16-row blocks (value block, gate block); the output
@@ -76,7 +81,7 @@ typedef struct CcvGemm {
     int32_t M, N, K, taps;
     int32_t lda, ldc, ldr, ldb2; /* ldb2: row stride of bias2 (>= N) */
     int32_t a_f32;          /* 0: A is bf16, 1: A is fp32 (converted on load) */
-    int32_t gather;         /* 0 linear, 1 conv3x3, 2 tconv3 */
+    int32_t gather;         /* 0 linear, 1 conv3x3, 2 tconv3, 3 stacked segments */
     int32_t out_h, out_w;   /* gather 1: output image size */
     int32_t src_h, src_w;   /* gather 1: stored source image size (before upsample) */
     int32_t stride;         /* gather 1: 1 or 2 */
@@ -84,7 +89,7 @@ typedef struct CcvGemm {
     int32_t no_lead_pad;    /* gather 1: 0 = one pixel of zero padding on every side (padding=1); 1 = zero padding only
                              * after the last row / column: F.pad(x, (0,1,0,1)) + stride-2 conv of the first-stage
                              * encoder's Downsample (lvdm/modules/networks/ae_modules.py:106-110) */
-    int32_t frames, hw;     /* gather 2: frames per clip, pixels per frame */
+    int32_t frames, hw;     /* gather 2: frames per clip, pixels per frame; gather 3: hw = rows between segments (>= M) */
     int32_t rows_per_batch; /* bias2 row = m / rows_per_batch */
     int32_t act;            /* 0 none, 1 SiLU, 2 GELU(erf), 3 ReLU */
     int32_t geglu;          /* 0/1 */
@@ -280,6 +285,12 @@ int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint3
 int ccv_epipolar_mask_bits_rect(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
                                 int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t W, int32_t downsample, int32_t patch_order,
                                 void* stream);
+/* Host-side view of the sparse attention kernel's per-XCD work queues (no device work; tests): the kernel gives each of the 8
+ * XCDs a longest-first queue of (batch-head slice, rank) items -- the slices s with s % 8 == xq in full plus an equal share of
+ * one leftover slice -- so that an XCD's L2 holds the K/V of ~1-3 slices instead of all of them.  Returns the length of queue
+ * `xq`; for 0 <= idx < length also *bh / *rank of item idx (rank >= ngroups: padding, skipped by the kernel).  Reference
+ * call site of the attention itself: model/modules/epipolar.py:75-102. */
+int64_t ccv_attn_sparse_queue_item(int32_t nbh, int32_t ngroups, int32_t xq, int64_t idx, int32_t* bh, int32_t* rank);
 /* Schedule of the sparse attention kernel (once per clip, after the mask was packed on the same stream):
  * order[b][r] = index of the 64-query group with the r-th largest popcount of its wave_bits row (ties: lower index first).
  * wave_bits [B, ngroups, wave_words], order [B, ngroups] int32; ngroups <= 8192. */

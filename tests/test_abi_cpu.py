@@ -100,3 +100,36 @@ def test_gemm_planner_host_logic(built):
     p = built.CcvGemm()
     tile, split = ctypes.c_int32(0), ctypes.c_int32(0)
     assert built.lib().ccv_gemm_plan(ctypes.byref(p), ctypes.byref(tile), ctypes.byref(split)) != 0
+
+
+@pytest.mark.parametrize("nbh,ngroups", [(10, 256), (20, 64), (40, 16), (8, 100), (3, 17), (1, 5), (13, 33), (64, 7)])
+def test_sparse_attention_xcd_queues_cover_every_item_once(built, nbh, ngroups):
+    """Host logic of the sparse attention kernel's work distribution (`ccv_attn_sparse_queue_item`, the same inline function the
+    kernel decodes its counter values with): the 8 per-XCD queues hold every (slice, rank) pair exactly once, ranks never
+    decrease within a queue (longest-first order survives the merge), home slices stay on their XCD, a leftover slice is
+    shared only by the XCDs assigned to it, and the queues are balanced to within one block of ranks."""
+    L = built.lib()
+    bh, rank = ctypes.c_int32(), ctypes.c_int32()
+    seen, lens = {}, []
+    for xq in range(8):
+        n = L.ccv_attn_sparse_queue_item(nbh, ngroups, xq, -1, None, None)
+        last, valid = -1, 0
+        for i in range(n):
+            assert L.ccv_attn_sparse_queue_item(nbh, ngroups, xq, i, ctypes.byref(bh), ctypes.byref(rank)) == n
+            assert 0 <= bh.value < nbh and rank.value >= last
+            last = rank.value
+            if rank.value >= ngroups:
+                continue                      # padding item: skipped by the kernel
+            valid += 1
+            assert (bh.value, rank.value) not in seen
+            seen[(bh.value, rank.value)] = xq
+            if bh.value < 8 * (nbh // 8):
+                assert bh.value % 8 == xq     # home slices are private to their XCD
+        lens.append(valid)
+    assert len(seen) == nbh * ngroups
+    n_extra = nbh % 8
+    for s in range(8 * (nbh // 8), nbh):      # leftover slice k is worked on by the XCDs with xq % n_extra == k only
+        owners = {x for (b, _), x in seen.items() if b == s}
+        assert owners <= {x for x in range(8) if x % n_extra == s - 8 * (nbh // 8)}
+    if nbh == 10 and ngroups == 256:          # the 32x32-latent launch of the benchmark: 320 items per XCD
+        assert lens == [320] * 8

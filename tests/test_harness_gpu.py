@@ -1,0 +1,102 @@
+"""The generation harness end to end on the GPU: eval_config.yaml -> model through the plugin
+mechanism -> (checkpoint) -> test batches with the reference dataset's keys -> `model.log_images` (get_batch_input, 25-step
+CFG DDIM, first-stage decode) -> per-sample directories in the layout of utils/save_video.py:65-157."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+FILES = ["camera_data.npy", "captions.txt", "context_0.png", "context_1.png", "generated.mp4", "ground_truth.mp4"]
+
+
+def _eval_config(model_section, out_dir, n, res, video_length=16, n_ctx=2):
+    """What 02_generate_videos.py:format_config_file leaves in eval_config.yaml, restricted to the keys the harness reads."""
+    return {"model": model_section,
+            "data": {"target": "main.utils_data.DataModuleFromConfig", "params": {
+                "batch_size": 1, "num_workers": 0, "test_max_n_samples": n,
+                "test": {"target": "data.realestate10k.RealEstate10K", "params": {
+                    "data_dir": "/nonexistent/realestate10k/test", "video_length": video_length, "frame_stride": 8, "resolution": [res, res],
+                    "additional_cond_frames": "random_back", "num_additional_cond_frames": n_ctx}}}},
+            "lightning": {"trainer": {"devices": 1, "num_nodes": 1}, "callbacks": {"batch_logger": {"target": "callbacks.ImageLogger", "params": {
+                "to_local": True, "log_all_gpus": True, "test_directory": str(out_dir), "log_images_kwargs": {
+                    "ddim_steps": 25, "ddim_eta": 1.0, "unconditional_guidance_scale": 7.5, "timestep_spacing": "uniform_trailing",
+                    "guidance_rescale": 0.7, "sampled_img_num": 1, "enable_camera_condition": True}}}}}}
+
+
+def test_generate_from_eval_config_full_size(tmp_path, golden_dir):
+    """The shipped CamContextI2V-256 config (reference yaml `model:` section), two synthetic clips at 256x256."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import generate
+    from camc2v_amd.video_io import read_mjpeg_mp4
+    model_section = copy.deepcopy(json.load(open(os.path.join(golden_dir, "model_configs.json")))["camcontexti2v_256"]["model"])
+    model_section["pretrained_checkpoint"] = str(tmp_path / "missing.ckpt")
+    cfg_path = tmp_path / "eval_config.yaml"
+    yaml.safe_dump(_eval_config(model_section, tmp_path / "test", 2, 256), open(cfg_path, "w"))
+    with pytest.raises(FileNotFoundError):           # no checkpoint and no --random-init: refuse, do not sample from garbage silently
+        generate.main([str(cfg_path)])
+    assert generate.main([str(cfg_path), "--random-init"]) == 0
+    dirs = sorted(os.listdir(tmp_path / "test"))
+    assert dirs == ["synthetic_00000", "synthetic_00001"]
+    for d in dirs:
+        p = tmp_path / "test" / d
+        assert sorted(os.listdir(p)) == FILES
+        assert np.load(p / "camera_data.npy").shape == (16, 19)
+        assert open(p / "captions.txt").read().strip().endswith("_fs=8")
+        try:
+            frames, fps = read_mjpeg_mp4(p / "generated.mp4")
+        except ValueError:                           # h264 through torchvision where that is installed
+            continue
+        assert frames.shape == (16, 256, 256, 3) and fps == pytest.approx(7.0)
+        assert frames.std() > 1.0                    # an image, not a constant
+    torch.cuda.empty_cache()
+
+
+def test_generate_small_model_from_checkpoint_matches_log_images(tmp_path):
+    """A reduced-width model saved as a Lightning-style checkpoint with the legacy `framestride_embed` names and foreign
+    prefixes: the harness loads it through load_checkpoints and its generated.mp4 holds exactly the frames that calling
+    log_images on the same batch in this process produces."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import configs, harness
+    from camc2v_amd.data import SyntheticRealEstate, collate
+    from camc2v_amd.video_io import read_mjpeg_mp4
+    from oracle.golden_inputs import SMALL_CFG
+    feeders = copy.deepcopy(configs.FEEDERS_256)
+    feeders["pose_encoder_config"]["params"]["channels"] = [64, 128, 256, 256]
+    feeders["multi_latent_adaptor"]["params"]["num_queries"] = 64                     # 8x8 latents per frame
+    model_section = {"target": "model.camcontexti2v.CamContextI2V", "pretrained_checkpoint": str(tmp_path / "small.ckpt"), "params": dict(
+        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": dict(SMALL_CFG)},
+        linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4, image_size=[8, 8], scale_factor=0.18215,
+        use_zero_conv_latent_input=True, multi_cond_strategy="token_concat_latent_epipolar", first_stage_key="video",
+        cond_stage_key="caption", uncond_type="empty_seq", add_type="add_to_main_branch",
+        epipolar_config=dict(origin_h=64, origin_w=64, is_3d_full_attn=False, num_register_tokens=4, attention_resolution=[8, 4, 2, 1],
+                             add_small_perturbation_on_zero_T=False), **feeders)}
+    cfg = _eval_config(model_section, tmp_path / "test", 1, 64)
+    dev = torch.device("cuda:0")
+    model = harness.build_model({"model": dict(model_section, pretrained_checkpoint=None)}, dev, random_init=True)
+    sd = {k.replace("fps_embedding", "framestride_embed"): v.detach().cpu() for k, v in model.state_dict().items()}
+    sd["cond_stage_model.model.positional_embedding"] = torch.zeros(77, 8)
+    sd["logvar"] = torch.zeros(1000)
+    torch.save({"state_dict": sd, "global_step": 50000}, tmp_path / "small.ckpt")
+    batch = collate([SyntheticRealEstate(num_samples=1, resolution=[64, 64], num_additional_cond_frames=2)[0]])
+    kw = cfg["lightning"]["callbacks"]["batch_logger"]["params"]["log_images_kwargs"]
+    torch.manual_seed(11)
+    logs = model.log_images(copy.deepcopy(batch), split="test", use_graph=True, **kw)
+    assert set(logs) >= {"samples", "gt_video", "image_condition", "reconst", "condition", "camera_data", "video_path", "cond_frames", "depth_scale"}
+    assert logs["samples"].shape == (1, 3, 16, 64, 64) and torch.isfinite(logs["samples"]).all()
+    del model
+    torch.manual_seed(11)
+    written = harness.generate(cfg, device=dev)
+    assert [os.path.basename(w) for w in written] == ["synthetic_00000"] and sorted(os.listdir(written[0])) == FILES
+    try:
+        frames, _ = read_mjpeg_mp4(os.path.join(written[0], "generated.mp4"))
+    except ValueError:
+        return
+    want = (((logs["samples"][0].permute(1, 2, 3, 0).float().cpu() + 1) / 2) * 255).clamp(0, 255).to(torch.uint8).numpy()
+    assert np.abs(frames.astype(int) - want.astype(int)).mean() < 3.0              # same clip up to JPEG q=95

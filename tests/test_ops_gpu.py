@@ -667,3 +667,29 @@ def test_sampler_camera_guidance_vs_reference_fixture(ops, golden_dir):
         s.p_sample_ddim(x, {"tag": "c", "camera_condition": {}}, t, index=2, unconditional_guidance_scale=7.5,
                         unconditional_conditioning={"tag": "uc"}, enable_camera_condition=True, camera_cfg=2.0,
                         camera_cfg_scheduler="linear")
+
+
+@pytest.mark.parametrize("cfg", ["auto", "ring2", "ring5s2", "fam45", "fam22"])
+def test_gemm_stacked_segments(ops, cfg, monkeypatch):
+    """gather 3: `taps` stacked operands [taps][seg_rows][K] against W = [W_0 | W_1 | W_2] -- three linear maps into one
+    output as one GEMM (the fused stream update of a camera-conditioned temporal block) -- on every kernel family:
+    planner's choice, LDS-ring tiles (unsplit / split-K), family tiles; ragged M, padded segments."""
+    env = {"auto": {}, "ring2": {"CCV_GEMM_RING": "2"}, "ring5s2": {"CCV_GEMM_RING": "5", "CCV_GEMM_SPLIT": "2"},
+           "fam45": {"CCV_GEMM_RING": "-1", "CCV_GEMM_FAMTILE": "45"}, "fam22": {"CCV_GEMM_RING": "-1", "CCV_GEMM_FAMTILE": "22"}}[cfg]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    M, seg, N, K, taps = 1024 + 40, 1100, 320, 640, 3
+    a = rnd(taps * seg, K, seed=300)
+    w = rnd(N, taps * K, seed=301, scale=0.03)
+    bias, res = rnd(N, seed=302, dtype=torch.float32), rnd(M, N, seed=303, dtype=torch.float32)
+    ref = sum(a[t * seg:t * seg + M].float() @ w[:, t * K:(t + 1) * K].float().t() for t in range(taps)) + bias
+    out = ops.gemm(a, w, k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=seg, bias=bias, residual=res, out_f32=True)
+    assert_close(out, ref + res, 2e-3, f"segments {cfg}")
+    stream = res.clone()       # in place, as the model uses it
+    ops.gemm(a, w, k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=seg, bias=bias, residual=stream, out_f32=True, out=stream)
+    assert torch.equal(stream, out)
+    from camc2v_amd.lib import CcvError
+    with pytest.raises(CcvError):
+        ops.gemm(a, w, k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=M - 8, out_f32=True)   # segments would overlap
+    with pytest.raises(CcvError):
+        ops.gemm(a[:2 * seg], w, k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=seg, out_f32=True)   # third segment missing

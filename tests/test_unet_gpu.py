@@ -398,3 +398,17 @@ def test_cfg_pair_falls_back_when_halves_do_not_share_the_camera(small):
     # the sampler's shared copy (same tensors + the is_uc marker) does take the batched path
     shared = dict(uncond, camera_condition=dict(cam, is_uc=True))
     assert core._same_extras(cond, shared) and not core._same_extras(cond, uncond)
+
+
+def test_fused_camera_projections_equal_three_gemms(small, monkeypatch):
+    """x += attn1.to_out(o1) + pluker_projection(n + P) + epipolar.to_out(o2) as ONE stacked-operand GEMM (K = 3C) against
+    the three separate stream updates: same numbers up to the fp32 summation order."""
+    from camc2v_amd import unet as unet_mod
+    unet, fx, _, _, g, cam, _ = small
+    assert unet_mod.FUSE_CAMERA_PROJECTIONS
+    y_fused = unet(g["x"], g["t"], context=g["ctx_rep"], fs=g["fs"], camera_condition=cam)
+    monkeypatch.setattr(unet_mod, "FUSE_CAMERA_PROJECTIONS", False)
+    y_three = unet(g["x"], g["t"], context=g["ctx_rep"], fs=g["fs"], camera_condition=cam)
+    _check(y_fused, fx["y_cam_rep"], "fused camera projections vs reference fixture")
+    _check(y_three, fx["y_cam_rep"], "three separate projections vs reference fixture")
+    _check(y_fused, y_three, "fused vs separate", 5e-2, 8e-2)      # this fixture amplifies any rounding difference (see header)
