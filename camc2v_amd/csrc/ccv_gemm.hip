@@ -1097,6 +1097,234 @@ int dispatch_tile(const CcvGemm& p, int ring, hipStream_t st) {
     return launch<2, 2, A_F32, GATHER, 32>(p, st);
 }
 
+// -------------------------------------------------------------------------------------------------
+// A-stationary kernel for the short-K linear layers of the 32x32-latent blocks (K = 320: QKV / out / GEGLU-up
+// projections over M = 32768 token rows).  There the tiled kernels above are bound by neither MFMA nor HBM: with five
+// 64-deep slabs per tile every workgroup spends its life in prologue (first DMA round trip), five exposed DMA
+// latencies and an epilogue, and re-fetches its 128 activation rows once per N tile (472 MB into LDS for the QKV
+// projection, profiles/r01_l2_lds_probe.txt).  Here one workgroup per CU owns 128 rows for the WHOLE N range:
+//   * its activation fragments (128 x K bf16) are loaded ONCE, straight from global memory into registers
+//     (40 x 16 B per lane at K = 320; one wave per SIMD, so the 512-register budget is there) and stay;
+//   * the weights stream through a 3-deep LDS ring in strips of 64 output columns x K (40 KiB, LDS-DMA, same
+//     swizzled 128-byte-row slab image as gemm_dma_kernel), two strips ahead of the MFMAs, behind counted vmcnt waits;
+//   * per strip a wave multiplies its 64 rows x 32 columns (4 x 2 accumulators of v_mfma_f32_16x16x32_bf16, weights
+//     as the A operand like everywhere in this file) and runs the epilogue for it while the next strips' DMA flies:
+//     LDS traffic is the weight fragments only (2 ds_read_b128 per 8 MFMAs), operand bytes into LDS drop from
+//     472 MB to 157 MB per QKV projection, and stores of strip s overlap the MFMAs of strip s + 1.
+// EST = vector stores one wave issues per strip epilogue (counted in vmcnt next to the DMA pieces).
+// -------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vm_only() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+enum { AS_BF16_WIDE = 0, AS_BF16 = 1, AS_F32 = 2, AS_GEGLU = 3 };
+
+template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256, 1) void gemm_astat_kernel(const CcvGemm p) {
+    constexpr int BM = 128, BN = 64, MT = 4, NT = 2, KS = 2 * NSLAB, K = 64 * NSLAB;
+    constexpr int STAGE = NSLAB * BN * 128;            // bytes of one weight strip in LDS
+    constexpr int NST = 3;                             // ring depth
+    constexpr int PIECES = NSLAB * BN / 8 / 4;         // DMA wave-instructions per wave and strip (8 rows x 128 B each)
+    constexpr int EST = MODE == AS_BF16_WIDE ? MT : MODE == AS_GEGLU ? MT : MT * NT;
+    static_assert((NSLAB * BN / 8) % 4 == 0 && PIECES + 2 * EST <= 63, "strip geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int nstrips = p.N / BN;
+
+    // ---- this wave's activation fragments: rows m0 + 64 wm + 16 i + fr, k = 32 ks + 8 fg .. + 7 ----------------------
+    bf16x8 fa[KS][MT];
+    {
+        const uint16_t* A = static_cast<const uint16_t*>(p.A);
+        static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int m = min(m0 + wm * 64 + 16 * i + fr, p.M - 1);
+            const uint16_t* ap = A + (long)m * p.lda + 8 * fg;
+            static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
+                constexpr int ks = decltype(Q)::value;
+                fa[ks][i] = *reinterpret_cast<const bf16x8*>(ap + 32 * ks);
+            });
+        });
+    }
+
+    // ---- weight strip DMA: piece q of this wave = slab q / 2, row group 4 (q & 1) + wave (8 rows x 128 B) -------------
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const uint16_t* wsrc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = 8 * (4 * h + wave) + lrow;        // row of the strip (0..63)
+        wsrc[h] = p.W + (long)r * K + ((lchunk ^ ((r >> 1) & 7)) << 3);
+    }
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
+    // Past the last strip the same number of pieces is issued from the zero line (into a stage nobody reads any more): every
+    // iteration then issues exactly PIECES DMA operations, so the counted waits below -- and the ones hipcc derives for the
+    // epilogue operands -- hold on every path without a conservative vmcnt(0).
+    auto issue = [&](int strip, int stage) {
+        const bool real = strip < nstrips;
+        const long soff = (long)strip * BN * K;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const int h = q & 1, slab = q >> 1;
+            __builtin_amdgcn_global_load_lds((gptr_t*)(real ? wsrc[h] + soff + slab * 64 : zero),
+                                             (lptr_t*)(smem + stage * STAGE + (slab * BN + 8 * (4 * h + wave)) * 128), 16, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    // Retire the activation loads where hipcc can see it: its waitcnt bookkeeping would otherwise keep them "pending" at the
+    // loop head and drain vmcnt(0) -- i.e. every weight strip in flight -- in front of the first MFMA of every iteration.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[ks][i]));
+
+    // HAS_BIAS / HAS_RES are compile-time so that these loads are unconditional: behind a branch hipcc's wait for them becomes
+    // vmcnt(0) and drains the weight strips in flight
+    static_assert(!HAS_RES || MODE == AS_F32, "residual needs the fp32 output mode");
+    for (int s = 0; s < nstrips; ++s) {
+        const int stage = s % NST;
+        const int n = s * BN + wn * 32 + 4 * fg;       // this lane's columns: n .. n+3 (fragment 0) and n+16 .. n+19 (fragment 1)
+        // strip s must have landed: younger operations of this wave that may stay in flight are the stores of the last two
+        // epilogues and the DMA of strip s + 1 (s >= 2), see the issue order below
+        if (s == 0) wait_vm_only<PIECES>();
+        else if (s == 1) wait_vm_only<PIECES + EST>();
+        else wait_vm_only<PIECES + 2 * EST>();
+        asm volatile("s_barrier" ::: "memory");
+        // Epilogue operands of this strip (bias, residual) are requested BEFORE the next DMA and waited for with a counted
+        // vmcnt(PIECES) of our own: hipcc's waitcnt pass answers mixed pending loads / stores / LDS-DMA with vmcnt(0), which
+        // would drain the weight strips in flight in front of every epilogue.  The loads are inline asm (invisible to that
+        // pass); the "+v" operands of the wait below order every use after it.
+        f32x4 bz[NT], rz[HAS_RES ? MT : 1][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (HAS_BIAS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bz[j]) : "v"(p.bias + n + 16 * j) : "memory");
+            else bz[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rz[i][j])
+                                 : "v"(p.residual + (long)(m0 + wm * 64 + 16 * i + fr) * p.ldr + n + 16 * j) : "memory");
+        }
+        // stage (s + 2) % 3 was read during iteration s - 1: every wave is past that (barrier above)
+        issue(s + 2, (s + 2) % NST);
+
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sB = smem + stage * STAGE;
+        bf16x8 fb[2][NT];   // weight fragments, one k-step ahead of the MFMAs
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<64>(wn * 32 + 16 * j + fr, fg));
+        static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            if constexpr (ks + 1 < KS) {
+                constexpr int slab = (ks + 1) >> 1;
+                const int c = ((ks + 1) & 1) * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sB + slab * BN * 128 + lds_off<64>(wn * 32 + 16 * j + fr, c));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks & 1][j], fa[ks][i], acc[i][j], 0, 0, 0);
+        });
+
+        // ---- epilogue of the strip: alpha, bias, (residual); exactly EST vector stores per lane ----------------------------
+        if constexpr (HAS_RES) {
+            static_assert(MT == 4 && NT == 2, "operand list below");
+            asm volatile("s_waitcnt vmcnt(%10)" : "+v"(bz[0]), "+v"(bz[1]), "+v"(rz[0][0]), "+v"(rz[0][1]), "+v"(rz[1][0]), "+v"(rz[1][1]),
+                         "+v"(rz[2][0]), "+v"(rz[2][1]), "+v"(rz[3][0]), "+v"(rz[3][1]) : "n"(PIECES) : "memory");
+        } else if constexpr (HAS_BIAS) {
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bz[0]), "+v"(bz[1]) : "n"(PIECES) : "memory");
+        }
+        static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            const int m = m0 + wm * 64 + 16 * i + fr;     // M % 128 == 0 (host check): always in range
+            float o[NT][4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                o[j][0] = acc[i][j][0] * p.alpha + bz[j][0]; o[j][1] = acc[i][j][1] * p.alpha + bz[j][1];
+                o[j][2] = acc[i][j][2] * p.alpha + bz[j][2]; o[j][3] = acc[i][j][3] * p.alpha + bz[j][3];
+            }
+            if constexpr (MODE == AS_GEGLU) {             // fragment 0 = value columns, fragment 1 = their gates
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[0][r] * gelu_erf_f(o[1][r]);
+                const int nc = (n >> 5) * 16 + (n & 15);
+                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            } else if constexpr (MODE == AS_F32) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float4 v4 = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+                    if constexpr (HAS_RES) { v4.x += rz[i][j][0]; v4.y += rz[i][j][1]; v4.z += rz[i][j][2]; v4.w += rz[i][j][3]; }
+                    *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n + 16 * j) = v4;
+                }
+            } else {
+                uint16_t* crow = static_cast<uint16_t*>(p.C) + (long)m * p.ldc;
+                const uint2 a2 = make_uint2(pack_bf16x2(o[0][0], o[0][1]), pack_bf16x2(o[0][2], o[0][3]));
+                const uint2 b2 = make_uint2(pack_bf16x2(o[1][0], o[1][1]), pack_bf16x2(o[1][2], o[1][3]));
+                if constexpr (MODE == AS_BF16_WIDE) {
+                    store_pair_bf16(crow, n, a2, b2);
+                } else {
+                    *reinterpret_cast<uint2*>(crow + n) = a2;
+                    *reinterpret_cast<uint2*>(crow + n + 16) = b2;
+                }
+            }
+        });
+    }
+}
+
+template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
+int launch_astat(const CcvGemm& p, hipStream_t st) {
+    constexpr size_t lds = 3 * (size_t)NSLAB * 64 * 128;
+    auto kern = gemm_astat_kernel<NSLAB, MODE, HAS_BIAS, HAS_RES>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.M / 128), dim3(256), lds, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm(a-stationary)");
+    return CCV_OK;
+}
+
+// The A-stationary kernel takes the problem when one 128-row workgroup per CU covers M with at most a quarter of the chip idle,
+// K fits the register-resident activation tile and nothing but a plain linear map is asked for.
+constexpr int ASTAT_TILE = -4;   // ccv_gemm_plan's *tile code for it
+inline bool astat_fits(const CcvGemm& p) {
+    static const bool on = [] { const char* e = getenv("CCV_GEMM_ASTAT"); return !(e && e[0] == '0'); }();   // A/B aid
+    if (!on || tune_env("CCV_GEMM_RING") != -2 || tune_env("CCV_GEMM_FAMTILE") != -2 || tune_env("CCV_GEMM_SPLIT") > 0) return false;
+    return p.gather == 0 && p.taps == 1 && !p.a_f32 && p.K == 320 && p.M % 128 == 0 && p.M / 128 >= 192 && p.M / 128 <= 512 &&
+           p.N % 64 == 0 && p.N >= 128 && p.act == 0 && p.bias2 == nullptr && (p.out_f32 || p.residual == nullptr) &&
+           (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+           (p.residual == nullptr || (reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
+}
+template <int MODE>
+int dispatch_astat_mode(const CcvGemm& p, hipStream_t st) {
+    if constexpr (MODE == AS_F32) {
+        if (p.residual) return p.bias ? launch_astat<5, MODE, true, true>(p, st) : launch_astat<5, MODE, false, true>(p, st);
+    }
+    return p.bias ? launch_astat<5, MODE, true, false>(p, st) : launch_astat<5, MODE, false, false>(p, st);
+}
+inline int dispatch_astat(const CcvGemm& p, hipStream_t st) {
+    if (p.geglu) return dispatch_astat_mode<AS_GEGLU>(p, st);
+    if (p.out_f32) return dispatch_astat_mode<AS_F32>(p, st);
+    const bool wide = (p.ldc & 7) == 0;
+    return wide ? dispatch_astat_mode<AS_BF16_WIDE>(p, st) : dispatch_astat_mode<AS_BF16>(p, st);
+}
+
 }  // namespace
 
 inline bool plan_ok(const CcvGemm& p) {
@@ -1105,6 +1333,7 @@ inline bool plan_ok(const CcvGemm& p) {
 
 extern "C" int64_t ccv_gemm_ws_bytes(const CcvGemm* pp) {
     if (pp == nullptr || !plan_ok(*pp)) return 0;
+    if (astat_fits(*pp)) return 0;
     const Plan pl = make_plan(*pp, true);
     return pl.split > 1 ? (int64_t)pl.split * pp->M * pp->N * (int64_t)sizeof(float) : 0;
 }
@@ -1112,6 +1341,11 @@ extern "C" int64_t ccv_gemm_ws_bytes(const CcvGemm* pp) {
 extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
     CCV_REQUIRE(pp && tile && split, CCV_EINVAL, "ccv_gemm_plan: null pointer");
     CCV_REQUIRE(plan_ok(*pp), CCV_ESHAPE, "ccv_gemm_plan: bad problem sizes");
+    if (astat_fits(*pp)) {
+        *tile = ASTAT_TILE;
+        *split = 1;
+        return CCV_OK;
+    }
     const Plan pl = make_plan(*pp, true);
     *tile = pl.ring;
     *split = pl.split;
@@ -1150,6 +1384,7 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(!p.bias2 || (p.rows_per_batch > 0 && p.ldb2 >= p.N && p.ldb2 % 4 == 0), CCV_EINVAL,
                 "ccv_gemm: bias2 needs rows_per_batch > 0 and ldb2 >= N (multiple of 4)");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (plan_ok(p) && astat_fits(p)) return dispatch_astat(p, st);
     switch (p.gather) {
         case 0:
             CCV_REQUIRE(p.taps == 1, CCV_EINVAL, "ccv_gemm: linear gather needs taps == 1");

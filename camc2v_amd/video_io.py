@@ -4,7 +4,7 @@ utils/save_video.py:65-157 ``log_evaluation``, utils/save_video.py:234-251 ``pre
     <save_dir>/<video name>/generated.mp4      the sampled clip
                             ground_truth.mp4   the input clip
                             camera_data.npy    the clip's camera rows (RealEstate10K text-file layout)
-                            captions.txt       one caption per line, with the frame stride appended ("..._fs=8")
+                            captions.txt       one caption per line, with the frame stride appended ("..._fs=8.0")
                             context_<j>.png    the extra context frames
                             condition.png      (optional) the conditioning frame
 

@@ -47,7 +47,7 @@ def test_generate_from_eval_config_full_size(tmp_path, golden_dir):
         p = tmp_path / "test" / d
         assert sorted(os.listdir(p)) == FILES
         assert np.load(p / "camera_data.npy").shape == (16, 19)
-        assert open(p / "captions.txt").read().strip().endswith("_fs=8")
+        assert open(p / "captions.txt").read().strip().endswith("_fs=8.0")   # str(fs.item()) of the float frame stride, as the reference writes it
         try:
             frames, fps = read_mjpeg_mp4(p / "generated.mp4")
         except ValueError:                           # h264 through torchvision where that is installed

@@ -693,3 +693,54 @@ def test_gemm_stacked_segments(ops, cfg, monkeypatch):
         ops.gemm(a, w, k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=M - 8, out_f32=True)   # segments would overlap
     with pytest.raises(CcvError):
         ops.gemm(a[:2 * seg], w, k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=seg, out_f32=True)   # third segment missing
+
+
+@pytest.mark.parametrize("kind", ["qkv", "out_res", "proj_f32", "geglu", "bf16_bias", "narrow_ldc"])
+def test_gemm_a_stationary_short_k(ops, kind, monkeypatch):
+    """The A-stationary kernel (one workgroup per CU keeps its 128 activation rows in registers, weight strips stream
+    through a 3-deep LDS ring) on the short-K linear layers of the 32x32-latent blocks: every epilogue flavour against fp32
+    torch, the plan reports tile code -4, and CCV_GEMM_ASTAT-independent shapes (K != 320, small M) still take the tiled kernels."""
+    monkeypatch.setattr(ops, "TRACK_GEMM_PLAN", True)
+    M, K = 24576, 320
+    a = rnd(M, K, seed=400)
+    if kind == "qkv":                       # fused QKV projection: bf16 out, no bias
+        w = rnd(960, K, seed=401, scale=0.05)
+        out = ops.gemm(a, w)
+        assert ops.LAST_GEMM_PLAN == (-4, 1)
+        assert_close(out, a.float() @ w.float().t(), 1e-2, kind)
+    elif kind == "out_res":                 # attention output projection accumulating into the fp32 stream, in place
+        w, bias = rnd(320, K, seed=402, scale=0.05), rnd(320, seed=403, dtype=torch.float32)
+        res = rnd(M, 320, seed=404, dtype=torch.float32)
+        ref = a.float() @ w.float().t() + bias + res
+        stream = res.clone()
+        ops.gemm(a, w, bias=bias, residual=stream, out_f32=True, out=stream)
+        assert ops.LAST_GEMM_PLAN == (-4, 1)
+        assert_close(stream, ref, 2e-3, kind)
+        assert_close(ops.gemm(a, w, residual=res, out_f32=True, alpha=0.5), 0.5 * (a.float() @ w.float().t()) + res, 2e-3, kind + " alpha, no bias")
+    elif kind == "proj_f32":                # proj_in: fp32 out, bias, no residual
+        w, bias = rnd(320, K, seed=405, scale=0.05), rnd(320, seed=406, dtype=torch.float32)
+        assert_close(ops.gemm(a, w, bias=bias, out_f32=True), a.float() @ w.float().t() + bias, 2e-3, kind)
+        assert ops.LAST_GEMM_PLAN == (-4, 1)
+    elif kind == "geglu":
+        from camc2v_amd.pack import interleave_geglu
+        wg, bg = rnd(2560, K, seed=407, scale=0.05), rnd(2560, seed=408, dtype=torch.float32)
+        wp, bp = interleave_geglu(wg, bg)
+        val, gate = (a.float() @ wg.float().t() + bg).chunk(2, dim=-1)
+        out = ops.gemm(a, wp, bias=bp, geglu=True)
+        assert ops.LAST_GEMM_PLAN == (-4, 1) and out.shape == (M, 1280)
+        assert_close(out, val * F.gelu(gate), 1.5e-2, kind)
+    elif kind == "bf16_bias":
+        w, bias = rnd(320, K, seed=409, scale=0.05), rnd(320, seed=410, dtype=torch.float32)
+        assert_close(ops.gemm(a, w, bias=bias), a.float() @ w.float().t() + bias, 1e-2, kind)
+        assert ops.LAST_GEMM_PLAN == (-4, 1)
+    else:                                   # output rows that are not 16-byte aligned: the 8-byte store variant
+        w = rnd(320, K, seed=411, scale=0.05)
+        buf = torch.zeros(M, 324, dtype=torch.bfloat16, device=dev())
+        out = ops.gemm(a, w, out=buf[:, :320])
+        assert ops.LAST_GEMM_PLAN == (-4, 1) and buf[:, 320:].abs().max().item() == 0
+        assert_close(out, a.float() @ w.float().t(), 1e-2, kind)
+    # outside its range the planner still answers with the tiled kernels
+    ops.gemm(rnd(4096, K, seed=412), rnd(320, K, seed=413))
+    assert ops.LAST_GEMM_PLAN[0] != -4
+    ops.gemm(rnd(M, 640, seed=414), rnd(320, 640, seed=415))
+    assert ops.LAST_GEMM_PLAN[0] != -4
