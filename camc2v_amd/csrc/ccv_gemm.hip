@@ -1102,15 +1102,14 @@ int dispatch_tile(const CcvGemm& p, int ring, hipStream_t st) {
 // projections over M = 32768 token rows).  There the tiled kernels above are bound by neither MFMA nor HBM: with five
 // 64-deep slabs per tile every workgroup spends its life in prologue (first DMA round trip), five exposed DMA
 // latencies and an epilogue, and re-fetches its 128 activation rows once per N tile (472 MB into LDS for the QKV
-// projection, profiles/r01_l2_lds_probe.txt).  Here one workgroup per CU owns 128 rows for the WHOLE N range:
+// projection, profiles/r01_l2_lds_probe.txt).  Here one 8-wave workgroup per CU owns 128 rows for the WHOLE N range:
 //   * its activation fragments (128 x K bf16) are loaded ONCE, straight from global memory into registers
-//     (40 x 16 B per lane at K = 320; one wave per SIMD, so the 512-register budget is there) and stay;
+//     (20 x 16 B per lane at K = 320) and stay;
 //   * the weights stream through a 3-deep LDS ring in strips of 64 output columns x K (40 KiB, LDS-DMA, same
 //     swizzled 128-byte-row slab image as gemm_dma_kernel), two strips ahead of the MFMAs, behind counted vmcnt waits;
-//   * per strip a wave multiplies its 64 rows x 32 columns (4 x 2 accumulators of v_mfma_f32_16x16x32_bf16, weights
+//   * per strip a wave multiplies its 32 rows x 32 columns (2 x 2 accumulators of v_mfma_f32_16x16x32_bf16, weights
 //     as the A operand like everywhere in this file) and runs the epilogue for it while the next strips' DMA flies:
-//     LDS traffic is the weight fragments only (2 ds_read_b128 per 8 MFMAs), operand bytes into LDS drop from
-//     472 MB to 157 MB per QKV projection, and stores of strip s overlap the MFMAs of strip s + 1.
+//     LDS traffic is the weight fragments only, operand bytes into LDS drop from 472 MB to 157 MB per QKV projection.
 // EST = vector stores one wave issues per strip epilogue (counted in vmcnt next to the DMA pieces).
 // -------------------------------------------------------------------------------------------------
 template <int N>
@@ -1121,13 +1120,23 @@ __device__ __forceinline__ void wait_vm_only() {
 enum { AS_BF16_WIDE = 0, AS_BF16 = 1, AS_F32 = 2, AS_GEGLU = 3 };
 
 template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
-__global__ __launch_bounds__(256, 1) void gemm_astat_kernel(const CcvGemm p) {
-    constexpr int BM = 128, BN = 64, MT = 4, NT = 2, KS = 2 * NSLAB, K = 64 * NSLAB;
+__global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
+    // 8 waves = 4 (rows) x 2 (columns), wave tile 32 rows x 32 columns, two waves per SIMD.  Measured on the way here
+    // (profiles/r02_astat_notes.txt): 4 waves of 64 rows, one per SIMD, add the phases up (knock-out: MFMA 9.6 us + stores 7.8 us
+    // + weight DMA 5.3 us over a 17.8 us floor for the QKV projection, 36.4 us); 8 waves: 32.5 us; letting waves 4-7 run their
+    // epilogue one strip late (under the other half's MFMAs) or holding a whole strip's fragments in registers: slower again.
+    // s_memtime stamps: per strip ~3100 cycles (wait + barrier 680, DMA issue + 40 MFMAs 1630, epilogue 800) and a 14k-cycle
+    // prologue (160 KiB of activation fragments per CU arrive at ~11 B/clk/CU): the kernel is bound by vector issue (short K:
+    // ~6 VALU instructions per output element against 2.5 MFMAs) and that prologue, not by MFMA, LDS or HBM.
+    constexpr int BM = 128, BN = 64, MT = 2, NT = 2, KS = 2 * NSLAB, K = 64 * NSLAB, NWAVE = 8;
     constexpr int STAGE = NSLAB * BN * 128;            // bytes of one weight strip in LDS
     constexpr int NST = 3;                             // ring depth
-    constexpr int PIECES = NSLAB * BN / 8 / 4;         // DMA wave-instructions per wave and strip (8 rows x 128 B each)
-    constexpr int EST = MODE == AS_BF16_WIDE ? MT : MODE == AS_GEGLU ? MT : MT * NT;
-    static_assert((NSLAB * BN / 8) % 4 == 0 && PIECES + 2 * EST <= 63, "strip geometry");
+    constexpr int PIECES = NSLAB * BN / 8 / NWAVE;     // DMA wave-instructions per wave and strip (8 rows x 128 B each)
+    constexpr int EST = MODE == AS_BF16_WIDE ? MT : MODE == AS_GEGLU ? MT : MT * NT;     // vector stores per strip epilogue
+    constexpr int NL = (HAS_BIAS ? NT : 0) + (HAS_RES ? MT * NT : 0);                    // epilogue-operand loads per strip
+    static_assert(BN / 8 == NWAVE && PIECES == NSLAB && 2 * PIECES + 2 * EST + NL <= 63, "strip geometry: wave w stages row group w of every slab");
+    static_assert(!HAS_RES || MODE == AS_F32, "residual needs the fp32 output mode");
+    static_assert(MT == 2 && NT == 2, "operand lists of the counted waits below");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1136,13 +1145,35 @@ __global__ __launch_bounds__(256, 1) void gemm_astat_kernel(const CcvGemm p) {
     const int m0 = blockIdx.x * BM;
     const int nstrips = p.N / BN;
 
-    // ---- this wave's activation fragments: rows m0 + 64 wm + 16 i + fr, k = 32 ks + 8 fg .. + 7 ----------------------
+    // diagnosis (tools/astat_stamps.py passes a buffer in p.ws): wave 0 of every workgroup stamps s_memtime at the phase borders
+    unsigned long long* stamps = (p.ws != nullptr && wave == 0 && lane == 0) ? static_cast<unsigned long long*>(p.ws) + (long)blockIdx.x * (2 + 3 * nstrips) : nullptr;
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
+
+    // ---- weight strip DMA: piece q of this wave = slab q, row group `wave` (8 rows x 128 B) ---------------------------
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const int wr = 8 * wave + lrow;                     // row of the strip (0..63) this lane fetches
+    const uint16_t* wsrc = p.W + (long)wr * K + ((lchunk ^ ((wr >> 1) & 7)) << 3);
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
+    // Past the last strip the same number of pieces is issued from the zero line (into a stage nobody reads any more): every
+    // iteration then issues exactly PIECES DMA operations, so the counted waits below hold on every path.
+    auto issue = [&](int strip, int stage) {
+        const bool real = strip < nstrips;
+        const long soff = (long)strip * BN * K;
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(real ? wsrc + soff + q * 64 : zero),
+                                             (lptr_t*)(smem + stage * STAGE + (q * BN + 8 * wave) * 128), 16, 0, 0);
+    };
+    issue(0, 0);      // before the activation loads: the first strips' round trip runs under them
+    issue(1, 1);
+
+    // ---- this wave's activation fragments: rows m0 + 32 wm + 16 i + fr, k = 32 ks + 8 fg .. + 7 ----------------------
     bf16x8 fa[KS][MT];
     {
         const uint16_t* A = static_cast<const uint16_t*>(p.A);
         static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            const int m = min(m0 + wm * 64 + 16 * i + fr, p.M - 1);
+            const int m = min(m0 + wm * 16 * MT + 16 * i + fr, p.M - 1);
             const uint16_t* ap = A + (long)m * p.lda + 8 * fg;
             static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
                 constexpr int ks = decltype(Q)::value;
@@ -1150,108 +1181,47 @@ __global__ __launch_bounds__(256, 1) void gemm_astat_kernel(const CcvGemm p) {
             });
         });
     }
-
-    // ---- weight strip DMA: piece q of this wave = slab q / 2, row group 4 (q & 1) + wave (8 rows x 128 B) -------------
-    const int lrow = lane >> 3, lchunk = lane & 7;
-    const uint16_t* wsrc[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = 8 * (4 * h + wave) + lrow;        // row of the strip (0..63)
-        wsrc[h] = p.W + (long)r * K + ((lchunk ^ ((r >> 1) & 7)) << 3);
-    }
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
-    // Past the last strip the same number of pieces is issued from the zero line (into a stage nobody reads any more): every
-    // iteration then issues exactly PIECES DMA operations, so the counted waits below -- and the ones hipcc derives for the
-    // epilogue operands -- hold on every path without a conservative vmcnt(0).
-    auto issue = [&](int strip, int stage) {
-        const bool real = strip < nstrips;
-        const long soff = (long)strip * BN * K;
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            const int h = q & 1, slab = q >> 1;
-            __builtin_amdgcn_global_load_lds((gptr_t*)(real ? wsrc[h] + soff + slab * 64 : zero),
-                                             (lptr_t*)(smem + stage * STAGE + (slab * BN + 8 * (4 * h + wave)) * 128), 16, 0, 0);
-        }
-    };
-
-    issue(0, 0);
-    issue(1, 1);
-    // Retire the activation loads where hipcc can see it: its waitcnt bookkeeping would otherwise keep them "pending" at the
-    // loop head and drain vmcnt(0) -- i.e. every weight strip in flight -- in front of the first MFMA of every iteration.
+    // Retire the activation loads where hipcc can see it (this is a vmcnt(0): the two strips issued above land with them): its
+    // waitcnt bookkeeping would otherwise keep them "pending" at the loop head and drain every weight strip in flight in front
+    // of the first MFMA of every iteration.
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[ks][i]));
+    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
 
-    // HAS_BIAS / HAS_RES are compile-time so that these loads are unconditional: behind a branch hipcc's wait for them becomes
-    // vmcnt(0) and drains the weight strips in flight
-    static_assert(!HAS_RES || MODE == AS_F32, "residual needs the fp32 output mode");
-    for (int s = 0; s < nstrips; ++s) {
-        const int stage = s % NST;
-        const int n = s * BN + wn * 32 + 4 * fg;       // this lane's columns: n .. n+3 (fragment 0) and n+16 .. n+19 (fragment 1)
-        // strip s must have landed: younger operations of this wave that may stay in flight are the stores of the last two
-        // epilogues and the DMA of strip s + 1 (s >= 2), see the issue order below
-        if (s == 0) wait_vm_only<PIECES>();
-        else if (s == 1) wait_vm_only<PIECES + EST>();
-        else wait_vm_only<PIECES + 2 * EST>();
-        asm volatile("s_barrier" ::: "memory");
-        // Epilogue operands of this strip (bias, residual) are requested BEFORE the next DMA and waited for with a counted
-        // vmcnt(PIECES) of our own: hipcc's waitcnt pass answers mixed pending loads / stores / LDS-DMA with vmcnt(0), which
-        // would drain the weight strips in flight in front of every epilogue.  The loads are inline asm (invisible to that
-        // pass); the "+v" operands of the wait below order every use after it.
-        f32x4 bz[NT], rz[HAS_RES ? MT : 1][NT];
+    // Epilogue operands (bias, residual) are inline-asm loads with counted waits of our own: hipcc's waitcnt pass answers mixed
+    // pending loads / stores / LDS-DMA with vmcnt(0), which would drain the weight strips in flight.  HAS_BIAS / HAS_RES are
+    // compile-time so that the loads are unconditional (uniform operation counts).
+    auto load_operands = [&](int strip, f32x4 (&bz)[NT], f32x4 (&rz)[MT][NT]) {
+        const int n = strip * BN + wn * 32 + 4 * fg;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if constexpr (HAS_BIAS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bz[j]) : "v"(p.bias + n + 16 * j) : "memory");
             else bz[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if constexpr (HAS_RES) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rz[i][j])
-                                 : "v"(p.residual + (long)(m0 + wm * 64 + 16 * i + fr) * p.ldr + n + 16 * j) : "memory");
-        }
-        // stage (s + 2) % 3 was read during iteration s - 1: every wave is past that (barrier above)
-        issue(s + 2, (s + 2) % NST);
-
-        f32x4 acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const unsigned char* sB = smem + stage * STAGE;
-        bf16x8 fb[2][NT];   // weight fragments, one k-step ahead of the MFMAs
-#pragma unroll
-        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<64>(wn * 32 + 16 * j + fr, fg));
-        static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
-            constexpr int ks = decltype(Q)::value;
-            if constexpr (ks + 1 < KS) {
-                constexpr int slab = (ks + 1) >> 1;
-                const int c = ((ks + 1) & 1) * 4 + fg;
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sB + slab * BN * 128 + lds_off<64>(wn * 32 + 16 * j + fr, c));
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (HAS_RES)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rz[i][j])
+                                 : "v"(p.residual + (long)(m0 + wm * 16 * MT + 16 * i + fr) * p.ldr + n + 16 * j) : "memory");
+                else rz[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks & 1][j], fa[ks][i], acc[i][j], 0, 0, 0);
-        });
-
-        // ---- epilogue of the strip: alpha, bias, (residual); exactly EST vector stores per lane ----------------------------
-        if constexpr (HAS_RES) {
-            static_assert(MT == 4 && NT == 2, "operand list below");
-            asm volatile("s_waitcnt vmcnt(%10)" : "+v"(bz[0]), "+v"(bz[1]), "+v"(rz[0][0]), "+v"(rz[0][1]), "+v"(rz[1][0]), "+v"(rz[1][1]),
-                         "+v"(rz[2][0]), "+v"(rz[2][1]), "+v"(rz[3][0]), "+v"(rz[3][1]) : "n"(PIECES) : "memory");
-        } else if constexpr (HAS_BIAS) {
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bz[0]), "+v"(bz[1]) : "n"(PIECES) : "memory");
-        }
+    };
+    // alpha, bias, (residual), store: exactly EST vector stores per lane.  WAITN: operations younger than this strip's operand
+    // loads that may stay in flight (the "+v" operands order every use of the loaded values behind the wait).
+    auto epilogue = [&](auto WAITN, int strip, f32x4 (&acc)[MT][NT], f32x4 (&bz)[NT], f32x4 (&rz)[MT][NT]) __attribute__((always_inline)) {
+        constexpr int waitn = decltype(WAITN)::value;
+        if constexpr (HAS_RES)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(bz[0]), "+v"(bz[1]), "+v"(rz[0][0]), "+v"(rz[0][1]), "+v"(rz[1][0]), "+v"(rz[1][1]) : "n"(waitn) : "memory");
+        else if constexpr (HAS_BIAS)
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bz[0]), "+v"(bz[1]) : "n"(waitn) : "memory");
+        const int n = strip * BN + wn * 32 + 4 * fg;   // this lane's columns: n .. n+3 (fragment 0) and n+16 .. n+19 (fragment 1)
         static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            const int m = m0 + wm * 64 + 16 * i + fr;     // M % 128 == 0 (host check): always in range
+            const int m = m0 + wm * 16 * MT + 16 * i + fr;     // M % 128 == 0 (host check): always in range
             float o[NT][4];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -1283,7 +1253,58 @@ __global__ __launch_bounds__(256, 1) void gemm_astat_kernel(const CcvGemm p) {
                 }
             }
         });
+    };
+
+    // Vector-memory operations of a wave, in issue order (vmcnt counts them in this order), iteration s:
+    //     L(s) [NL]   DMA(s+2) [PIECES]   (MFMA s)   <wait L(s): PIECES younger>   stores(s) [EST]
+    // Top of iteration s: strip s (DMA issued in iteration s-2) must have landed; younger than it are PIECES (DMA s+1) and the
+    // stores (and operand loads) of the min(s, 2) epilogues since; the counts below never exceed the true number of younger
+    // operations (a smaller count only waits for more).
+    f32x4 acc[MT][NT], bz[NT], rz[MT][NT];
+    for (int s = 0; s < nstrips; ++s) {
+        const int stage = s % NST;
+        const int ne = s >= 2 ? 2 : s;
+        if (ne == 0) wait_vm_only<PIECES>();
+        else if (ne == 1) wait_vm_only<PIECES + EST>();
+        else wait_vm_only<PIECES + 2 * EST>();
+        asm volatile("s_barrier" ::: "memory");
+        if (stamps) stamps[2 + 3 * s] = __builtin_amdgcn_s_memtime();
+        load_operands(s, bz, rz);
+        asm volatile("" ::: "memory");
+        // stage (s + 2) % 3 was read during iteration s - 1: every wave is past that (barrier above)
+        issue(s + 2, (s + 2) % NST);
+
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char* sB = smem + stage * STAGE;
+        bf16x8 fb[2][NT];   // weight fragments, one k-step ahead of the MFMAs
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(sB + lds_off<64>(wn * 32 + 16 * j + fr, fg));
+        static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            if constexpr (ks + 1 < KS) {
+                constexpr int slab = (ks + 1) >> 1;
+                const int c = ((ks + 1) & 1) * 4 + fg;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fb[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sB + slab * BN * 128 + lds_off<64>(wn * 32 + 16 * j + fr, c));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks & 1][j], fa[ks][i], acc[i][j], 0, 0, 0);
+        });
+        if (stamps) {   // after the MFMAs have produced their results (reading an accumulator waits for them)
+            asm volatile("" ::"v"(acc[MT - 1][NT - 1]));
+            stamps[3 + 3 * s] = __builtin_amdgcn_s_memtime();
+        }
+        epilogue(std::integral_constant<int, PIECES>{}, s, acc, bz, rz);
+        if (stamps) stamps[4 + 3 * s] = __builtin_amdgcn_s_memtime();
     }
+    wait_vm_only<0>();   // the zero-line pieces issued past the last strip target this workgroup's LDS: retire them before it is released
 }
 
 template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
@@ -1295,7 +1316,7 @@ int launch_astat(const CcvGemm& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.M / 128), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.M / 128), dim3(512), lds, st, p);
     CCV_LAUNCH_CHECK("ccv_gemm(a-stationary)");
     return CCV_OK;
 }

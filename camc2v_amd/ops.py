@@ -47,7 +47,7 @@ def _rows(t):
 # ---------------------------------------------------------------------------------------
 def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
          residual=None, act=ACT_NONE, geglu=False, out_f32=False, out=None, gather=GATHER_LINEAR,
-         conv=None, tconv=None, seg_rows=None, alpha=1.0):
+         conv=None, tconv=None, seg_rows=None, alpha=1.0, debug_ws=None):
     """out[m, n] = epilogue(sum_tap gather(a) @ w_tap^T).  See include/ccv.h (ccv_gemm).
 
     a: [rows, lda] bf16 or fp32 (2-D, last dim contiguous); w: [N, taps*K] bf16.
@@ -128,6 +128,8 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     if ws_bytes > 0:  # split-K workspace for long-K / few-tile problems
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         p.ws, p.ws_bytes = _ptr(ws), ws_bytes
+    if debug_ws is not None:   # diagnosis: the A-stationary kernel stamps its phases into this buffer (tools/astat_stamps.py)
+        p.ws, p.ws_bytes = _ptr(debug_ws), debug_ws.numel() * debug_ws.element_size()
     global LAST_GEMM_PLAN
     if TRACK_GEMM_PLAN:
         tile, split = C.c_int32(0), C.c_int32(0)
