@@ -334,6 +334,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--same-conditioning", action="store_true", help="every clip reuses clip 0's tensors (round-1 behaviour)")
+    ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
     args = ap.parse_args(argv)
     hooks = hooks or {}
 
@@ -397,7 +398,7 @@ def main(argv=None, hooks=None):
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        extras = on_gpu and hooks.get("extras", True)
+        extras = on_gpu and hooks.get("extras", True) and not args.clips_only
         dom = dominant_kernel(model, device, sets[0]) if extras else None
         skipped = skipped_flops(sets[0]) if extras else None
         line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen)
