@@ -108,7 +108,9 @@ int ccv_gemm(const CcvGemm* p, void* stream);
  * the tuning tools; no device work): *tile = index of the LDS-ring tile configuration (0: 128x320, 1: 64x320,
  * 2: 128x160, 3: 64x160 4-deep, 4: 64x160 8-deep, 5: 128x320 2-deep at two workgroups per CU, 6: 128x160 2-deep, 7: 64x320 2-deep; the last two are tuning
  * candidates the planner does not pick), -1 for the 128x128-family kernels (two stages of 64-deep slabs) on the tile they
- * choose by workgroup count, -2 for that kernel on a 128x160 tile; *split = split-K factor. */
+ * choose by workgroup count, -2 for that kernel on a 128x160 tile, -4 for the A-stationary kernel (K = 320 linear layers over
+ * 24576 .. 65536 rows: one workgroup per CU keeps its 128 activation rows in registers, weights stream in 64-column strips);
+ * *split = split-K factor. */
 int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
 
 /* ------------------------------------------------------------------------------------

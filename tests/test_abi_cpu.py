@@ -81,8 +81,11 @@ def _plan(built, M, N, K, taps=1, gather=0, geglu=0, a_f32=0):
 def test_gemm_planner_host_logic(built):
     """Kernel selection is host code (no device work): the model's layer classes map to the kernels the sweep
     in profiles/ found fastest, and the workspace request always matches the planned split."""
-    assert _plan(built, 32768, 960, 320) == (-1, 1)                      # QKV projection: 128x128 family, unsplit
-    assert _plan(built, 32768, 2560, 320, geglu=1) == (5, 1)             # GEGLU up-projection: 2-stage 128x320 tile
+    assert _plan(built, 32768, 960, 320) == (-4, 1)                      # QKV projection at 32x32 latents (K = 320, M = 256 x 128): A-stationary kernel
+    assert _plan(built, 32768, 2560, 320, geglu=1) == (-4, 1)            # GEGLU up-projection there: the same
+    assert _plan(built, 16384, 960, 320) == (-1, 1)                      # a single (not CFG-paired) forward: 128 row tiles would idle half the chip
+    assert _plan(built, 8192, 5120, 640, geglu=1) == (5, 1)              # GEGLU up-projection at 16x16 latents: 2-stage 128x320 tile
+    assert _plan(built, 8192, 1920, 640) == (-1, 1)                      # QKV projection at 16x16 latents: 128x128 family, unsplit
     assert _plan(built, 512, 10240, 1280, geglu=1) == (-1, 1)            # ... unless its 128 tiles would leave CUs idle
     assert _plan(built, 2048, 1280, 5120) == (-2, 4)                     # FF down-projection at 8x8 latents: long K -> 128x160 family tile, split 4
     assert _plan(built, 512, 1280, 5120) == (-1, 4)                      # ... at 4x4 latents: 160 tiles, split-K 4
