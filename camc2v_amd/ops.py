@@ -203,6 +203,40 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
     return out
 
 
+def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wave_bits, mask_nb=1, group_order=None, kreg=None, vreg=None,
+                         perm=None, out=None, scale=None):
+    """fp8 (e4m3) variant of the masked epipolar attention: same q / k / v (bf16, strided) and masks as ``attention``; quantises
+    into a workspace (per-(batch, head) scales), then runs the sparse kernel on fp8 MFMA.  Returns bf16 [B*L, H*64]."""
+    _dev(q, k, v, mask_bits, wave_bits, kreg, vreg, out)
+    for t in (q, k, v, kreg, vreg):
+        if t is not None and t.dtype != BF16:
+            raise CcvError("attention_sparse_fp8: q/k/v must be bf16")
+    if mask_bits.dtype != torch.int32 or not mask_bits.is_contiguous() or wave_bits.dtype != torch.int32 or not wave_bits.is_contiguous():
+        raise CcvError("attention_sparse_fp8: mask_bits / wave_bits must be contiguous int32")
+    if out is None:
+        out = torch.empty((B * L, H * 64), dtype=BF16, device=q.device)
+    p = CcvAttn()
+    p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(out)
+    p.q_bso, p.q_bsi, p.q_ls = q_str
+    p.k_bso, p.k_bsi, p.k_ls = k_str
+    p.v_bso, p.v_bsi, p.v_ls = v_str
+    p.o_bso, p.o_bsi, p.o_ls = L * H * 64, 0, H * 64
+    p.B, p.inner, p.H, p.Lq, p.Lk = B, 1, H, L, L
+    p.scale = scale if scale is not None else 1.0 / math.sqrt(64.0)
+    p.mask_bits, p.mask_words, p.mask_bs, p.mask_nb = _ptr(mask_bits), mask_bits.shape[-1], mask_bits.shape[-2] * mask_bits.shape[-1], mask_nb
+    p.wave_bits, p.wave_words, p.wave_bs = _ptr(wave_bits), wave_bits.shape[-1], wave_bits.shape[-2] * wave_bits.shape[-1]
+    if group_order is not None:
+        p.group_order, p.order_bs = _ptr(group_order), group_order.shape[-1]
+    if kreg is not None:
+        p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
+    if perm is not None:
+        p.perm_hw, p.perm_w = perm
+    nbytes = lib().ccv_attn_fp8_ws_bytes(C.byref(p), None, None, None, None, None)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    check(lib().ccv_attn_sparse_fp8_fwd(C.byref(p), _ptr(ws), nbytes, _stream()), "ccv_attn_sparse_fp8_fwd")
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------

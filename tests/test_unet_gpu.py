@@ -412,3 +412,34 @@ def test_fused_camera_projections_equal_three_gemms(small, monkeypatch):
     _check(y_fused, fx["y_cam_rep"], "fused camera projections vs reference fixture")
     _check(y_three, fx["y_cam_rep"], "three separate projections vs reference fixture")
     _check(y_fused, y_three, "fused vs separate", 5e-2, 8e-2)      # this fixture amplifies any rounding difference (see header)
+
+
+def test_fp8_epipolar_attention_in_model(golden_dir, monkeypatch):
+    """BASELINE.json configs[4]: the UNet with the e4m3 epipolar attention (CCV_ATTN_FP8) on the medium fixture (16x16 latents,
+    L = 4096 tokens) against the reference's fp32 output: stated tolerance rel-L2 <= 3e-2 (bf16 path: 2.1e-2)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import camera, unet as unet_mod
+    from oracle import unet_oracle as uo
+    from oracle.golden_inputs import MEDIUM_CFG, SEED, medium_inputs
+    from utils.utils import instantiate_from_config
+    fx = np.load(os.path.join(golden_dir, "unet_medium.npz"))
+    man = json.load(open(os.path.join(golden_dir, "unet_medium_manifest.json")))
+    unet = instantiate_from_config({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": MEDIUM_CFG})
+    unet.enable_camera_conditioning(dict(origin_h=128, origin_w=128, is_3d_full_attn=False, num_register_tokens=4,
+                                         attention_resolution=[8, 4, 2, 1], compression_factor=1))
+    unet.epipolar_origin_h = 128
+    unet.load_state_dict(uo.seeded_state_dict(man, SEED), strict=True)
+    unet = unet.cuda().eval()
+    inp = medium_inputs()
+    packed = camera.epipolar_masks_packed(torch.from_numpy(fx["F128"]).cuda(), 16, 128, 128)
+    cam = dict(pluker_embedding_features=[f.cuda() for f in inp["feats"]], sample_locs_dict=None, sample_locs_packed=packed,
+               add_type="add_to_main_branch")
+    args = dict(context=inp["ctx_rep"].cuda(), fs=inp["fs"].cuda(), camera_condition=cam)
+    y16 = unet(inp["x"].cuda(), inp["t"].cuda(), **args)
+    monkeypatch.setattr(unet_mod, "FP8_EPIPOLAR", True)
+    y8 = unet(inp["x"].cuda(), inp["t"].cuda(), **args)
+    assert not torch.equal(y8, y16)                  # the e4m3 kernel did run (L = 4096 >= FP8_EPIPOLAR_MIN_TOKENS)
+    _check(y16, fx["y_cam_rep"], "medium, bf16 epipolar attention vs reference fixture", 2.5e-2, 5e-2)
+    _check(y8, fx["y_cam_rep"], "medium, e4m3 epipolar attention vs reference fixture", 3e-2, 6e-2)
+    _check(y8, y16, "e4m3 vs bf16 epipolar attention in the model", 2.5e-2, 6e-2)
