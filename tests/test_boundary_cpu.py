@@ -147,3 +147,19 @@ def test_get_batch_input_refuses_cpu_and_missing_encoders():
         model.get_batch_input(batch, random_uncond=True)
     with pytest.raises(CcvError):
         model.get_learned_conditioning(["a prompt"])
+
+
+def test_trajectory_extension_as_the_reference_writes_it():
+    """main/runtime.py:193-202: a 16-pose trajectory asked for 48 frames is extended by last @ (last^-1 @ c2ws) blocks."""
+    from main.runtime import extend_trajectory
+    from camc2v_amd.data import SyntheticRealEstate
+    c2w = torch.linalg.inv(SyntheticRealEstate(num_samples=1, resolution=[64, 64])[0]["RT"])
+    ext = extend_trajectory(c2w, 48)
+    assert ext.shape[0] >= 48 and torch.equal(ext[:16], c2w)
+    last = c2w[-1]
+    assert torch.allclose(ext[16:32], torch.einsum("ik,tkj->tij", last, torch.einsum("ik,tkj->tij", torch.linalg.inv(last), c2w)), atol=1e-5)
+    # the second replay starts from the end of the first: relative motion of frame j in replay 2 == in the original
+    rel0 = torch.linalg.inv(c2w[0]) @ c2w[5]
+    rel2 = torch.linalg.inv(ext[32]) @ ext[37]
+    assert torch.allclose(rel0, rel2, atol=1e-4)
+    assert extend_trajectory(c2w, 10) is c2w

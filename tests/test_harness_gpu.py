@@ -100,3 +100,48 @@ def test_generate_small_model_from_checkpoint_matches_log_images(tmp_path):
         return
     want = (((logs["samples"][0].permute(1, 2, 3, 0).float().cpu() + 1) / 2) * 255).clamp(0, 255).to(torch.uint8).numpy()
     assert np.abs(frames.astype(int) - want.astype(int)).mean() < 3.0              # same clip up to JPEG q=95
+
+
+def test_autoregressive_chunks_chain_on_the_last_frame(tmp_path):
+    """main/runtime.py:260-326 at reduced size: two 16-frame chunks; the second is conditioned on the first one's last generated
+    frame, the poses of the second chunk are the reference's extension of the trajectory, outputs are written per step and concatenated."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import configs, harness
+    from camc2v_amd.data import SyntheticRealEstate
+    from camc2v_amd.runtime import generate_autoregressive
+    from camc2v_amd.video_io import read_mjpeg_mp4
+    from oracle.golden_inputs import SMALL_CFG
+    feeders = copy.deepcopy(configs.FEEDERS_256)
+    feeders["pose_encoder_config"]["params"]["channels"] = [64, 128, 256, 256]
+    feeders["multi_latent_adaptor"]["params"]["num_queries"] = 64
+    model_section = {"target": "model.camcontexti2v.CamContextI2V", "pretrained_checkpoint": None, "params": dict(
+        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": dict(SMALL_CFG)},
+        linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4, image_size=[8, 8], scale_factor=0.18215,
+        use_zero_conv_latent_input=True, multi_cond_strategy="token_concat_latent_epipolar", add_type="add_to_main_branch",
+        epipolar_config=dict(origin_h=64, origin_w=64, is_3d_full_attn=False, num_register_tokens=4, attention_resolution=[8, 4, 2, 1]), **feeders)}
+    model = harness.build_model({"model": model_section}, torch.device("cuda:0"), random_init=True)
+    sample = SyntheticRealEstate(num_samples=1, resolution=[64, 64], num_additional_cond_frames=2)[0]
+    seen = []
+    orig = model.log_images
+
+    def spy(batch, **kw):
+        seen.append((batch["video"][0, :, 0].clone(), batch["RT"][0].clone()))
+        return orig(batch, **kw)
+
+    model.log_images = spy
+    full = generate_autoregressive(model, sample, auto_reg_steps=1, save_dir=str(tmp_path / "ar"), ddim_steps=5, ddim_eta=1.0,
+                                   unconditional_guidance_scale=3.5, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                   enable_camera_condition=True, use_graph=True)
+    assert full.shape == (1, 3, 32, 64, 64) and torch.isfinite(full).all()
+    assert len(seen) == 2
+    assert torch.allclose(seen[1][0].cpu(), full[0, :, 15], atol=1e-6)                    # chunk 2 starts from chunk 1's last frame
+    assert torch.allclose(seen[0][1].cpu(), sample["RT"], atol=1e-6)                      # chunk 1: the sample's own poses
+    assert torch.allclose(seen[1][1].cpu(), sample["RT"], atol=1e-4)                      # chunk 2: the reference's extension replays the trajectory
+    files = sorted(os.listdir(tmp_path / "ar"))
+    assert files == ["cond_step1.png", "cond_step2.png", "config.txt", "generated.mp4", "ground_truth.mp4", "step1.mp4", "step2.mp4"]
+    try:
+        frames, _ = read_mjpeg_mp4(tmp_path / "ar" / "generated.mp4")
+        assert frames.shape == (32, 64, 64, 3)
+    except ValueError:
+        pass
