@@ -1103,8 +1103,8 @@ int dispatch_tile(const CcvGemm& p, int ring, hipStream_t st) {
 // 64-deep slabs per tile every workgroup spends its life in prologue (first DMA round trip), five exposed DMA
 // latencies and an epilogue, and re-fetches its 128 activation rows once per N tile (472 MB into LDS for the QKV
 // projection, profiles/r01_l2_lds_probe.txt).  Here one 8-wave workgroup per CU owns 128 rows for the WHOLE N range:
-//   * its activation fragments (128 x K bf16) are loaded ONCE, straight from global memory into registers
-//     (20 x 16 B per lane at K = 320) and stay;
+//   * its activation tile (128 x K bf16) is staged ONCE through LDS in whole 128-byte lines (borrowing two ring stages) and
+//     read into registers (20 x 16 B per lane at K = 320), where it stays;
 //   * the weights stream through a 3-deep LDS ring in strips of 64 output columns x K (40 KiB, LDS-DMA, same
 //     swizzled 128-byte-row slab image as gemm_dma_kernel), two strips ahead of the MFMAs, behind counted vmcnt waits;
 //   * per strip a wave multiplies its 32 rows x 32 columns (2 x 2 accumulators of v_mfma_f32_16x16x32_bf16, weights
@@ -1164,30 +1164,42 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
             __builtin_amdgcn_global_load_lds((gptr_t*)(real ? wsrc + soff + q * 64 : zero),
                                              (lptr_t*)(smem + stage * STAGE + (q * BN + 8 * wave) * 128), 16, 0, 0);
     };
-    issue(0, 0);      // before the activation loads: the first strips' round trip runs under them
-    issue(1, 1);
-
-    // ---- this wave's activation fragments: rows m0 + 32 wm + 16 i + fr, k = 32 ks + 8 fg .. + 7 ----------------------
-    bf16x8 fa[KS][MT];
+    // Strip s lives in ring stage (s + 2) % 3: stages 0 and 1 first hold the ACTIVATION tile, staged by LDS-DMA in whole
+    // 128-byte lines (8 rows x 128 B per piece, [slab][128 rows][128 B], same source-side swizzle as the weight image) and read
+    // ONCE into registers: 80 KiB per workgroup from L2 instead of 160 KiB of fragment-shaped (16 rows x 64 B) loads issued twice
+    // (the two column halves of the wave grid need the same rows).  The first weight strip flies into stage 2 meanwhile.
+    issue(0, 2 % NST);
     {
         const uint16_t* A = static_cast<const uint16_t*>(p.A);
-        static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            const int m = min(m0 + wm * 16 * MT + 16 * i + fr, p.M - 1);
-            const uint16_t* ap = A + (long)m * p.lda + 8 * fg;
-            static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
-                constexpr int ks = decltype(Q)::value;
-                fa[ks][i] = *reinterpret_cast<const bf16x8*>(ap + 32 * ks);
-            });
-        });
+        constexpr int APIECES = NSLAB * (BM / 8) / NWAVE;     // 10 at K = 320
+        static_assert(NSLAB * BM * 128 <= 2 * STAGE, "the activation tile must fit the two stages it borrows");
+#pragma unroll
+        for (int q = 0; q < APIECES; ++q) {
+            const int pid = wave + NWAVE * q, slab = pid / (BM / 8), rg = pid % (BM / 8);
+            const int r = 8 * rg + lrow;
+            const uint16_t* src = A + (long)(m0 + r) * p.lda + slab * 64 + ((lchunk ^ ((r >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(smem + (slab * BM + 8 * rg) * 128), 16, 0, 0);
+        }
     }
-    // Retire the activation loads where hipcc can see it (this is a vmcnt(0): the two strips issued above land with them): its
-    // waitcnt bookkeeping would otherwise keep them "pending" at the loop head and drain every weight strip in flight in front
-    // of the first MFMA of every iteration.
+    wait_vm_only<0>();
+    asm volatile("s_barrier" ::: "memory");
+    // ---- this wave's activation fragments: rows 32 wm + 16 i + fr of the tile, k = 32 ks + 8 fg .. + 7 -----------------
+    bf16x8 fa[KS][MT];
+    static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
+        constexpr int ks = decltype(Q)::value;
+        constexpr int slab = ks >> 1;
+        const int c = (ks & 1) * 4 + fg;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            fa[ks][i] = *reinterpret_cast<const bf16x8*>(smem + slab * BM * 128 + lds_off<64>(wm * 16 * MT + 16 * i + fr, c));
+    });
+    // retire the fragment reads (an lgkmcnt(0) where hipcc can see it), then every wave is done with stages 0 / 1
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[ks][i]));
+    asm volatile("s_barrier" ::: "memory");
+    issue(1, (1 + 2) % NST);
     if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
 
     // Epilogue operands (bias, residual) are inline-asm loads with counted waits of our own: hipcc's waitcnt pass answers mixed
@@ -1262,7 +1274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     // operations (a smaller count only waits for more).
     f32x4 acc[MT][NT], bz[NT], rz[MT][NT];
     for (int s = 0; s < nstrips; ++s) {
-        const int stage = s % NST;
+        const int stage = (s + 2) % NST;
         const int ne = s >= 2 ? 2 : s;
         if (ne == 0) wait_vm_only<PIECES>();
         else if (ne == 1) wait_vm_only<PIECES + EST>();
@@ -1271,8 +1283,8 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
         if (stamps) stamps[2 + 3 * s] = __builtin_amdgcn_s_memtime();
         load_operands(s, bz, rz);
         asm volatile("" ::: "memory");
-        // stage (s + 2) % 3 was read during iteration s - 1: every wave is past that (barrier above)
-        issue(s + 2, (s + 2) % NST);
+        // strip s + 2 goes where strip s - 1 was (stage (s + 1) % 3), read during iteration s - 1: every wave is past that (barrier above)
+        issue(s + 2, (s + 4) % NST);
 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
