@@ -276,6 +276,42 @@ __device__ __attribute__((aligned(16))) unsigned char g_attn_zero_line[16];
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// V^T fragments of one 32-key block [32 rows x 128 B, 64-byte halves swapped on rows with ((row >> 1) & 1)] for the four
+// (16-key half s2, 32-column half d) PV MFMAs, read with ds_read_b64_tr_b16 from INLINE ASM.  Through
+// __builtin_amdgcn_ds_read_tr16_b64 hipcc's waitcnt pass puts an s_waitcnt vmcnt(0) in front of the first read (it
+// cannot tell that the LDS-DMA writes still in flight go to another ring stage), which drains the prefetch ring once
+// per block: the next block's DMA then overlaps only QK^T + softmax instead of the whole block.  The reads are waited for
+// here (lgkmcnt(0)): hipcc does not see them.
+__device__ __forceinline__ void read_vt_block(const unsigned char* sV, int lane, int hh, bf16x8 (&vf)[2][2]) {
+    const int li = lane & 15, g = (lane >> 4) & 1;
+    const int row0 = 4 * hh + (li >> 2);
+    const int x = ((row0 >> 1) & 1) << 6;
+    const int c = (16 * g + 4 * (li & 3)) * 2;                               // < 64: (c ^ x) = c + x, ((64 + c) ^ x) = c + (64 - x)
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(sV) + row0 * 128 + c;
+    const uint32_t ad0 = base + x, ad1 = base + 64 - x;
+    bf16x4 t0, t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %2, %9\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:3072\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:3072\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(ad0), "v"(ad1)
+        : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        vf[0][0][j] = t0[j]; vf[0][0][4 + j] = t1[j];
+        vf[0][1][j] = t2[j]; vf[0][1][4 + j] = t3[j];
+        vf[1][0][j] = t4[j]; vf[1][0][4 + j] = t5[j];
+        vf[1][1][j] = t6[j]; vf[1][1][4 + j] = t7[j];
+    }
+}
+
 // Online-softmax update of one 32-key x 32-query score block held as the 32x32x16 MFMA accumulator (lane = query
 // column lane&31, register i = key row (i&3) + 8 (i>>2) + 4 hh): mask -> running max -> rescale -> P = exp2(S c - m)
 // in bf16 fragments for the PV MFMA.  w = the query's 32 mask bits for this key block (ignored when all_visible,
@@ -783,24 +819,15 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         };
         if (on0) softmax_block(sa0, mw[0], m_run[0], l_run[0], oacc[0], pf0);
         if (on1) softmax_block(sa1, mw[1], m_run[1], l_run[1], oacc[1], pf1);
+        bf16x8 vf[2][2];
+        read_vt_block(sV, lane, hh, vf);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int kb0 = 16 * s2 + 4 * hh;
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                const int li = lane & 15, g = (lane >> 4) & 1;
-                const int row0 = kb0 + (li >> 2);
-                const int colb = (32 * d + 16 * g + 4 * (li & 3)) * 2;
-                const unsigned char* a0 = sV + row0 * 128 + (colb ^ (((row0 >> 1) & 1) << 6));
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * 128));
-                bf16x8 vf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                if (on0) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0[s2], oacc[0][d], 0, 0, 0);
-                if (on1) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1[s2], oacc[1][d], 0, 0, 0);
+                if (on0) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf0[s2], oacc[0][d], 0, 0, 0);
+                if (on1) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf1[s2], oacc[1][d], 0, 0, 0);
             }
-        }
     };
 
     // Retire every ordinary vector load (Q fragments, bitmap row) where hipcc can see it: its waitcnt bookkeeping

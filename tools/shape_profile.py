@@ -67,6 +67,8 @@ ops.layernorm = timed("ln", ops.layernorm, norm_key)
 model = bench.build_model(dev)
 cond, uncond, fs, x_T, noises = bench.synthetic_inputs(model, dev)
 t = torch.full((1,), 439, dtype=torch.long, device=dev)
+uncond = dict(uncond)
+uncond["camera_condition"] = dict(cond["camera_condition"], is_uc=True)   # what p_sample_ddim does (reference ddim.py:259-260)
 
 
 def forward():
