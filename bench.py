@@ -18,11 +18,13 @@ path (`scaling: weak`); one RCCL all_gather of the final latents closes the time
 report how many ranks took part.
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -136,12 +138,18 @@ def cpu_baseline(model, device, inputs):
                 seconds_per_cfg_step=sum(secs)), parity
 
 
-def timed_clips(sample_fn, steps, warmup, dist=None, sync=None, after=None):
+def timed_clips(sample_fn, steps, warmup, dist=None, sync=None, after=None, lanes=1, lane_ctx=None):
     """W untimed + exactly K timed calls of `sample_fn(i)`, bracketed by sync + barrier + sync on both sides;
     `after(last_output)` (the final all_gather) runs inside the timed region.  Returns (max-over-ranks wall seconds,
     this rank's wall seconds, last output, after's result).  Device independent so the multi-process logic is testable
-    on CPU with gloo."""
+    on CPU with gloo.
+
+    lanes > 1: that many clips are IN FLIGHT on this rank -- one host thread per lane, each inside `lane_ctx(l)` (on the
+    GPU: its own HIP stream, hence its own hipGraphs and static buffers); the lanes pull the K timed clip indices from one
+    shared counter, so exactly K clips are sampled whatever K is.  Every lane first runs the W warm-up clips itself (its
+    graphs are captured there), one lane after the other."""
     sync = sync or (lambda: None)
+    lane_ctx = lane_ctx or (lambda l: contextlib.nullcontext())
 
     def fence():
         sync()
@@ -149,13 +157,45 @@ def timed_clips(sample_fn, steps, warmup, dist=None, sync=None, after=None):
             dist.barrier()
         sync()
 
-    for i in range(warmup):
-        sample_fn(i)
-    fence()
-    t0 = time.perf_counter()
-    out = None
-    for i in range(steps):
-        out = sample_fn(warmup + i)
+    outs = {}
+    if lanes <= 1:
+        for i in range(warmup):
+            sample_fn(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            outs[i] = sample_fn(warmup + i)
+    else:
+        for l in range(lanes):
+            with lane_ctx(l):
+                for i in range(warmup):
+                    sample_fn(i)
+        fence()
+        lock, nxt, errors = threading.Lock(), [0], []
+
+        def lane(l):
+            try:
+                with lane_ctx(l):
+                    while True:
+                        with lock:
+                            i = nxt[0]
+                            nxt[0] += 1
+                        if i >= steps:
+                            break
+                        outs[i] = sample_fn(warmup + i)
+                    sync()
+            except BaseException as e:   # re-raised on the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=lane, args=(l,)) for l in range(lanes)]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+    out = outs.get(steps - 1)
     extra = after(out) if after is not None else None
     fence()
     mine = time.perf_counter() - t0
@@ -278,7 +318,7 @@ def skipped_flops(inputs):
     return epi_clip, kv_ref - kv_here
 
 
-def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None):
+def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None, lanes=1):
     from camc2v_amd import configs
     clips = steps * world
     tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
@@ -315,8 +355,11 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, "
                                "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights; every clip "
-                               "has its own conditioning tensors (per-clip prologue inside the timed region)",
-                   "clips_per_gpu": 1, "parallelism": f"clip-dp{world}", "launch": "hipGraph" if use_graph else "eager"},
+                               "has its own conditioning tensors (per-clip prologue inside the timed region); every sampling call "
+                               "is ONE clip (UNet batch 2 under CFG) -- clips_in_flight_per_gpu independent calls run on "
+                               "their own HIP streams at a time",
+                   "clips_per_gpu": 1, "clips_in_flight_per_gpu": lanes, "parallelism": f"clip-dp{world}",
+                   "launch": "hipGraph" if use_graph else "eager"},
         "roofline": roof,
     }
     if ranks_seen is not None:
@@ -346,11 +389,12 @@ def main(argv=None, hooks=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--same-conditioning", action="store_true", help="every clip reuses clip 0's tensors (round-1 behaviour)")
+    ap.add_argument("--lanes", type=int, default=2, help="independent clips in flight per GPU (one host thread + HIP stream + hipGraph set each)")
     ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
     args = ap.parse_args(argv)
     hooks = hooks or {}
@@ -397,18 +441,29 @@ def main(argv=None, hooks=None):
     first_ms = {}
 
     def one_clip(i):
-        if on_gpu and i == args.warmup:          # first timed clip: HIP event on the launch stream
+        if on_gpu and i == args.warmup and args.lanes <= 1:          # first timed clip: HIP event on the launch stream
             ev[0].record()
         t0 = time.perf_counter()
         out = run_clip(model, *sets[i % n_sets], use_graph)
-        if i == 0:
+        if i == 0 and "v" not in first_ms:
             sync()
             first_ms["v"] = 1e3 * (time.perf_counter() - t0)
         return out
 
-    elapsed, _, out, ranks_seen = timed_clips(one_clip, args.steps, args.warmup, dist, sync, gather_latents(dist, world))
+    lanes = max(1, min(args.lanes, args.steps))
+    lane_ctx = None
+    if on_gpu and lanes > 1:
+        streams = [torch.cuda.Stream(device) for _ in range(lanes)]
+
+        @contextlib.contextmanager
+        def lane_ctx(l):                       # device, grad mode and current stream are per host thread
+            torch.cuda.set_device(device)
+            with torch.no_grad(), torch.cuda.stream(streams[l]):
+                yield
+                streams[l].synchronize()
+    elapsed, _, out, ranks_seen = timed_clips(one_clip, args.steps, args.warmup, dist, sync, gather_latents(dist, world), lanes, lane_ctx)
     dev_ms = None
-    if on_gpu:
+    if on_gpu and lanes == 1:
         ev[1].record()
         torch.cuda.synchronize()
         dev_ms = ev[0].elapsed_time(ev[1])
@@ -418,9 +473,18 @@ def main(argv=None, hooks=None):
         extras = on_gpu and hooks.get("extras", True) and not args.clips_only
         dom = dominant_kernel(model, device, sets[0]) if extras else None
         skipped = skipped_flops(sets[0]) if extras else None
-        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen)
+        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen, lanes)
         if first_ms:
             line["config"]["first_clip_ms"] = first_ms["v"]    # includes packing, graph capture (a new signature) and caches
+        if world == 1 and extras and lanes > 1:      # the same clips one at a time (one stream), for comparison
+            run_clip(model, *sets[0], use_graph)         # this (the default) stream has no graphs yet: capture them untimed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(2):
+                run_clip(model, *sets[(args.warmup + i) % n_sets], use_graph)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            line["config"]["one_clip_at_a_time"] = {"frames_per_s": 16.0 / dt, "ms_per_clip": 1e3 * dt}
         if world == 1 and extras:
             line["config"]["two_clips_per_forward"] = two_clips_per_forward(model, device, use_graph, rank)
         if world == 1 and extras and not args.no_cpu_baseline:

@@ -14,6 +14,8 @@
 // per wave, 32x32 blocks whose mask words are all zero (both exact).  Register tokens are a
 // leading, always-visible K/V segment.  An optional second context (image tokens) is a second
 // softmax pass over the same Q tile, added with a gate.
+#include <atomic>
+
 #include "ccv_common.h"
 
 namespace {
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
     const long qitems = use_xcd_queues ? ccv_sparse_queue_items(nbh, ngroups, xq) : (long)nbh * ngroups;
   for (;;) {
     unsigned int idx = 0;
-    if (lane == 0) idx = atomicAdd(&g_sparse_ctr[slot][xq], 1u);
+    if (lane == 0) idx = atomicAdd(p.queue_counters ? p.queue_counters + xq : &g_sparse_ctr[slot][xq], 1u);
     const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
     if (item >= qitems) break;
     int bh, rank;
@@ -1034,16 +1036,17 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
         dim3 grid2((unsigned)nwg2);
         if (p.mask_bits && p.wave_bits && (p.variant == 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024)) {
             // persistent: 2 workgroups per CU (LDS-bound), fewer when there are fewer 64-query groups than waves
-            static int next_slot = 0;
+            static std::atomic<int> next_slot{0};
             static const int n_cu = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return n;
             }();
-            const int slot = (next_slot++) & 63;   // successive launches use different counter rows (streams may overlap)
+            const int slot = next_slot.fetch_add(1) & 63;   // successive launches use different counter rows; callers whose launches
+                                                            // overlap on several streams pass their own zeroed queue_counters
             const long groups = (long)((p.Lq + 63) / 64) * p.H * p.B;
             const long wgs = (groups + 3) / 4 < 2l * n_cu ? (groups + 3) / 4 : 2l * n_cu;
-            hipLaunchKernelGGL(sparse_ctr_reset, dim3(1), dim3(64), 0, st, slot);
+            if (!p.queue_counters) hipLaunchKernelGGL(sparse_ctr_reset, dim3(1), dim3(64), 0, st, slot);
             static const int xcd_queues = [] { const char* e = getenv("CCV_ATTN_XCD"); return e ? atoi(e) : 0; }();   // 0 (default): one chip-wide queue; 1: per-XCD queues
             // (HW_REG_XCC_ID); 2: per-XCD queues with blockIdx & 7 as the label.  Measured on MI355X (profiles/r02_sparse_xcd_queues.txt):
             // the XCD-local queues are SLOWER (32x32 latents 585 -> 621 us, 16x16 168 -> 208 us per b=2 launch), so they stay off

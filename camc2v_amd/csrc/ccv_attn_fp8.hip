@@ -12,6 +12,8 @@
 //                       and O^T += V^T P^T on v_mfma_f32_32x32x16_fp8_fp8 (P in e4m3, scales folded into the softmax scale
 //                       and the final normalisation); 5 DMA wave-instructions per block instead of 9.
 // Reference call site it serves: F.scaled_dot_product_attention in model/modules/epipolar.py:99.
+#include <atomic>
+
 #include "ccv_common.h"
 
 namespace {
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_fp8_kernel(const CcvAttn p
 
   for (;;) {
     unsigned int idx = 0;
-    if (lane == 0) idx = atomicAdd(&g_sparse8_ctr[slot], 1u);
+    if (lane == 0) idx = atomicAdd(p.queue_counters ? p.queue_counters : &g_sparse8_ctr[slot], 1u);
     const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
     if (item >= total) break;
     const int rank = (int)(item / nbh);
@@ -395,16 +397,16 @@ extern "C" int ccv_attn_sparse_fp8_fwd(const CcvAttn* pp, void* ws, int64_t ws_b
     a.q = reinterpret_cast<const uint16_t*>(q8);
     a.k = reinterpret_cast<const uint16_t*>(k8b);
     a.v = reinterpret_cast<const uint16_t*>(v8tb);
-    static int next_slot = 0;
+    static std::atomic<int> next_slot{0};
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const int slot = (next_slot++) & 63;
+    const int slot = next_slot.fetch_add(1) & 63;
     const long groups = (long)((p.Lq + 63) / 64) * nbh;
     const long wgs = (groups + 3) / 4 < 2l * n_cu ? (groups + 3) / 4 : 2l * n_cu;
-    hipLaunchKernelGGL(sparse8_ctr_reset, dim3(1), dim3(64), 0, st, slot);
+    if (!p.queue_counters) hipLaunchKernelGGL(sparse8_ctr_reset, dim3(1), dim3(64), 0, st, slot);
     hipLaunchKernelGGL(attn_sparse_fp8_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a, scales, nblk, slot);
     CCV_LAUNCH_CHECK("ccv_attn_sparse_fp8_fwd");
     return CCV_OK;

@@ -46,6 +46,7 @@ class CcvAttn(C.Structure):
         ("kreg", vp), ("vreg", vp), ("nreg", i32),
         ("perm_hw", i32), ("perm_w", i32),
         ("variant", i32),
+        ("queue_counters", vp),
     ]
 
 

@@ -186,6 +186,10 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
             p.flags_ktiles = tile_flags.shape[-1]
             p.flags_bs = tile_flags.shape[-2] * tile_flags.shape[-1]
         if wave_bits is not None:
+            # the persistent sparse kernel's work-queue counters: caller-owned and zeroed here, so that launches of several
+            # streams / replays of several graphs may overlap (no state kept in the library)
+            ctr = torch.zeros(8, dtype=torch.int32, device=q.device)
+            p.queue_counters = _ptr(ctr)
             p.wave_bits = _ptr(wave_bits)
             p.wave_words = wave_bits.shape[-1]
             p.wave_bs = wave_bits.shape[-2] * wave_bits.shape[-1]
@@ -225,6 +229,8 @@ def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wa
     p.scale = scale if scale is not None else 1.0 / math.sqrt(64.0)
     p.mask_bits, p.mask_words, p.mask_bs, p.mask_nb = _ptr(mask_bits), mask_bits.shape[-1], mask_bits.shape[-2] * mask_bits.shape[-1], mask_nb
     p.wave_bits, p.wave_words, p.wave_bs = _ptr(wave_bits), wave_bits.shape[-1], wave_bits.shape[-2] * wave_bits.shape[-1]
+    ctr = torch.zeros(8, dtype=torch.int32, device=q.device)     # caller-owned work-queue counter (see ``attention``)
+    p.queue_counters = _ptr(ctr)
     if group_order is not None:
         p.group_order, p.order_bs = _ptr(group_order), group_order.shape[-1]
     if kreg is not None:

@@ -13,6 +13,8 @@ schedule arithmetic as the reference sampler (``lvdm/models/samplers/ddim.py:10-
   * the camera dict is shared with the unconditional branch by reference (the reference
     deep-copies the 268 MB mask every step, ddim.py:258-260).
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -62,6 +64,10 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     a64 = a.double()
     sig = eta * torch.sqrt((1 - a_prev) / (1 - a64) * (1 - a64 / a_prev))
     return sig.float().numpy(), a.numpy(), a_prev.float().numpy()
+
+
+# one capture (and weight packing) at a time: captures of different lanes come from different host threads
+_CAPTURE_LOCK = threading.RLock()
 
 
 def _unet_of(model):
@@ -188,15 +194,21 @@ class _GraphedClip:
         cache = sampler.model.__dict__.setdefault("_ccv_graph_cache", {})
         unet = _unet_of(sampler.model)
         gen = getattr(unet, "weights_generation", 0)
-        for k in [k for k in cache if k[0] != gen]:      # graphs captured on weights that were since replaced
-            cache.pop(k)
         tree = cls._split(cond, kw)
-        key = (gen, tuple(x.shape), stochastic, _StaticTree.describe(tree))
-        hit = cache.get(key)
-        if hit is None:
-            while len(cache) >= cls.MAX_CACHED:
-                cache.pop(next(iter(cache)))
-            hit = cache[key] = cls(sampler, x, tree, stochastic)
+        # graphs (and their static conditioning buffers) belong to the stream they were captured on: a second clip in flight
+        # on another stream (bench.py --lanes, one host thread per lane) gets its own set instead of sharing buffers
+        lane = torch.cuda.current_stream(x.device).cuda_stream
+        key = (gen, tuple(x.shape), stochastic, _StaticTree.describe(tree), lane)
+        with _CAPTURE_LOCK:
+            for k in [k for k in cache if k[0] != gen]:      # graphs captured on weights that were since replaced
+                cache.pop(k)
+            hit = cache.get(key)
+            if hit is None:
+                lanes = {k[4] for k in cache} | {lane}
+                while sum(1 for k in cache if k[4] == lane) >= cls.MAX_CACHED or len(cache) >= cls.MAX_CACHED * len(lanes):
+                    victim = next((k for k in cache if k[4] == lane), next(iter(cache)))
+                    cache.pop(victim)
+                hit = cache[key] = cls(sampler, x, tree, stochastic)
         hit.sampler = sampler
         hit.load(tree)
         if isinstance(kw.get("unconditional_conditioning"), dict) and "camera_condition" in hit.static.tree["kw"]["unconditional_conditioning"]:
@@ -231,11 +243,11 @@ class _GraphedClip:
         if unet is not None and hasattr(unet, "inputs_only"):
             unet.forget_inputs(self.static.slots)      # the warm-up's derived tensors live outside any graph pool
             self.prologue = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.prologue):
+            with torch.cuda.graph(self.prologue, capture_error_mode="thread_local"):   # other lanes keep replaying meanwhile
                 with unet.inputs_only():
                     step()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.x_prev, self.pred_x0 = step()
         # the captures baked in the addresses of the UNet's derived inputs and packed weights: pin both
         self.keepalive = []

@@ -20,6 +20,7 @@ There is no CPU fallback: calling a forward with CPU tensors raises (the CPU res
 in ``oracle/`` and is test infrastructure only).
 """
 import math
+import threading
 from collections import OrderedDict, namedtuple
 
 import torch
@@ -47,6 +48,9 @@ def _dev_f32(p):
     return p.detach().float().contiguous()
 
 
+_PACK_LOCK = threading.RLock()
+
+
 class _Prepared:
     """Mixin: lazily packed device operands, dropped when parameters are (re)loaded or moved."""
 
@@ -56,10 +60,15 @@ class _Prepared:
         if cache is None or cache["dev"] != dev:
             if dev.type != "cuda":
                 raise CcvError(f"{type(self).__name__}: parameters live on {dev}; the product path is GPU only")
-            with torch.no_grad():
-                cache = self._pack()
-            cache["dev"] = dev
-            self.__dict__["_pk_cache"] = cache
+            with _PACK_LOCK:      # several host threads may drive the same module (one per clip in flight)
+                cache = self.__dict__.get("_pk_cache")
+                if cache is None or cache["dev"] != dev:
+                    with torch.no_grad():
+                        cache = self._pack()
+                    if not torch.cuda.is_current_stream_capturing():
+                        torch.cuda.current_stream(dev).synchronize()   # packed on this thread's stream, read from any
+                    cache["dev"] = dev
+                    self.__dict__["_pk_cache"] = cache
         return cache
 
     def invalidate(self):

@@ -162,6 +162,11 @@ typedef struct CcvAttn {
                          1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging;
                          3: as 0 but always the per-wave sparse kernel when wave_bits is given (0 picks it from 1024
                             64-query groups upwards and the tiled masked kernel below that) */
+    uint32_t* queue_counters; /* NULL or 8 uint32 that the caller ZEROED on `stream` before the call: the work-queue counters of
+                              * the persistent sparse kernel (wave_bits path).  With caller-owned counters the call keeps no
+                              * state in the library, so launches may overlap freely on different streams (two clips in
+                              * flight, two graphs replayed concurrently).  NULL: a row of the library's rotating pool of 64
+                              * counter rows, reset by a one-block launch in front of the kernel. */
 } CcvAttn;
 int ccv_attn_fwd(const CcvAttn* p, void* stream);
 /* Self-attention over Lq = Lk <= 16 tokens with an arbitrary head width (multiple of 8, <= 256): the temporal blocks of

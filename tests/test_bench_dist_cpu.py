@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, lanes=1, steps=3):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     import bench
@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_dir):
 
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        rc = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "2"],
+        rc = bench.main(["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--lanes", str(lanes)],
                         hooks=dict(device=torch.device("cpu"), backend="gloo", build_model=lambda dev: None,
                                    synthetic_inputs=make_inputs, sample_clip=fake_clip))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
@@ -68,6 +68,25 @@ def test_two_rank_bench_main(tmp_path):
     assert line["roofline"]["bound"] == "mfma" and line["vs_baseline"] is None and line["dtype"] == "bf16"
     assert set(line) >= {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                          "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def test_two_rank_bench_main_with_two_clips_in_flight(tmp_path):
+    """--lanes 2: every lane runs the W warm-up clips itself (its graphs are captured there), then the lanes share exactly K
+    timed clips (each sampled once, by whichever lane is free) and overlap them in time."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), 2, 4), nprocs=world, join=True)
+    r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(world)]
+    for i in range(world):
+        assert r[i]["rc"] == 0
+        assert r[i]["clips"][:4] == [0, 1, 0, 1]                      # warm-up: lane 0, then lane 1
+        assert sorted(r[i]["clips"][4:]) == [2, 3, 4, 5]              # exactly K = 4 timed clips, each once
+        assert r[i]["sets"] == 6
+    line = json.loads([ln for ln in r[0]["stdout"].splitlines() if ln.strip()][0])
+    assert line["steps"] == 4 and line["config"]["clips_in_flight_per_gpu"] == 2
+    # rank 1 sleeps 0.1 s per clip: 4 clips on 2 lanes take ~0.2 s, not 0.4 s
+    assert 50.0 - 5.0 <= line["ms_per_step"] <= 85.0
+    assert line["value"] == pytest.approx(16.0 * 4 * 2 / (line["ms_per_step"] * 4 / 1e3))
+    assert line["config"]["ranks_in_final_all_gather"] == 2
 
 
 def test_gpus_flag_must_match_the_launcher(monkeypatch):

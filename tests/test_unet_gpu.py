@@ -382,6 +382,66 @@ def test_one_graph_serves_new_clips_and_notices_new_weights(small):
         core.__dict__.pop("_ccv_graph_cache", None)
 
 
+def test_two_clips_in_flight_on_two_streams_equal_one_at_a_time(small):
+    """bench.py --lanes: two host threads, each on its own HIP stream, sample different clips concurrently through the SAME
+    model object.  Every stream gets its own hipGraphs and static conditioning buffers (graph cache keyed by stream), the
+    sparse attention's work-queue counters are caller-owned (CcvAttn.queue_counters), so the overlapping launches share no
+    state: every clip must come out bit-identical to sampling it alone."""
+    import threading
+    unet, fx, sd, _, g, cam, _ = small
+    core = _small_core(unet)
+    core.__dict__.pop("_ccv_graph_cache", None)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    noises = [torch.randn(2, 4, 16, 8, 8, device="cuda", generator=gen) for _ in range(3)]
+
+    def inputs(seed):
+        gg = torch.Generator(device="cuda").manual_seed(seed)
+        rn = lambda like: torch.randn(like.shape, device="cuda", generator=gg)
+        cam2 = dict(cam, pluker_embedding_features=[rn(f) * 0.1 for f in cam["pluker_embedding_features"]])
+        cc = rn(g["c_concat"])
+        return (dict(c_concat=[cc], c_crossattn=[rn(g["ctx_rep"])], camera_condition=cam2), dict(c_concat=[cc], c_crossattn=[rn(g["ctx_pf"])]),
+                rn(g["x"][:, :4]))
+
+    def clip(inp, use_graph=True):
+        cond, uncond, x_T = inp
+        s, _ = core.sample_log(cond, 2, True, 3, eta=1.0, x_T=x_T, unconditional_guidance_scale=7.5, unconditional_conditioning=dict(uncond),
+                               timestep_spacing="uniform_trailing", guidance_rescale=0.7, fs=g["fs"], enable_camera_condition=True,
+                               injected_noise=noises, use_graph=use_graph)
+        return s.clone()
+
+    sets = [inputs(100 + i) for i in range(6)]
+    torch.cuda.synchronize()
+    alone = [clip(x) for x in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got, errors = {}, []
+
+    def lane(l):
+        try:
+            torch.cuda.set_device(0)
+            with torch.no_grad(), torch.cuda.stream(streams[l]):
+                for rep in range(2):                 # the first pass captures this lane's graphs, the second replays them
+                    for i in range(l, len(sets), 2):
+                        got[(rep, i)] = clip(sets[i])
+                streams[l].synchronize()
+        except BaseException as e:
+            errors.append(e)
+
+    try:
+        threads = [threading.Thread(target=lane, args=(l,)) for l in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        lanes_cached = {k[4] for k in core.__dict__["_ccv_graph_cache"]}
+        assert len(lanes_cached) == 3                # the default stream's set + one per lane
+        for (rep, i), s in got.items():
+            assert torch.equal(s, alone[i]), f"clip {i} (pass {rep}) differs when another clip is in flight"
+    finally:
+        core.__dict__.pop("_ccv_graph_cache", None)
+
+
 def test_cfg_pair_falls_back_when_halves_do_not_share_the_camera(small):
     """A conditional dict with a camera but enable_camera_condition off: the reference's second apply_model runs WITHOUT
     the camera (ddim.py:258-263).  The batched 2b forward cannot express that, so apply_model_pair must take two forwards."""

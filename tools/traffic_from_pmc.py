@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""profiles/rNN_traffic.json from the two PMC summaries (tools/summarize_rocprof.py output of separate
+`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over `bench.py --steps 1 --warmup 1 --no-graph
+--clips-only --lanes 1`): L2<->fabric bytes per clip and per launch of the dominant kernel.  Counters are in KB;
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+    python tools/traffic_from_pmc.py <fetch_summary.txt> <write_summary.txt> <clips_in_run> <out.json> [kernel]"""
+import json
+import re
+import sys
+
+
+def read(path, counter, kernel):
+    total, per_launch, on = None, None, False
+    for line in open(path):
+        m = re.match(rf"# counter {counter}: total ([0-9.e+]+) over", line)
+        if m:
+            total, on = float(m.group(1)), True
+            continue
+        if on and line.startswith(kernel):
+            per_launch = float(line.split()[-1])
+            break
+    return total, per_launch
+
+
+fetch, write, clips, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+kernel = sys.argv[5] if len(sys.argv) > 5 else "attn_sparse_kernel"
+ft, fk = read(fetch, "FETCH_SIZE", kernel)
+wt, wk = read(write, "WRITE_SIZE", kernel)
+doc = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 1 --no-graph "
+              f"--clips-only --lanes 1` on MI355X, {fetch} / {write}; counters are in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md "
+              "prescribes for gfx950; L2<->fabric bytes (Infinity-Cache hits included)",
+    "clips_in_run": clips,
+    "bytes_per_clip": (2 * ft + wt) * 1024 / clips,
+    "dominant_kernel": kernel,
+    "dominant_kernel_bytes_per_launch": (2 * fk + wk) * 1024,
+}
+json.dump(doc, open(out, "w"), indent=1)
+print(json.dumps(doc, indent=1))
