@@ -10,7 +10,10 @@
  *     synchronously, so every entry point may be captured into a hipGraph;
  *   - return value: 0 = ok, negative = argument/shape error (CCV_E*), positive = the
  *     hipError_t of the failed launch; ccv_last_error() returns a thread-local message;
- *   - stateless and re-entrant; one process per GPU.
+ *   - stateless and re-entrant: any number of host threads may call in on different streams (the Python host samples two
+ *     clips at a time that way).  The one piece of device-side state, the work-queue counters of the persistent sparse
+ *     attention kernel, is caller-owned when CcvAttn.queue_counters is given (otherwise a rotating pool of 64 rows);
+ *     one process per GPU.
  *
  * Each entry point names the reference call site(s) it replaces (paths relative to
  * /root/reference/CamContextI2V).  The reference has no native code: every function
