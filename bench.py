@@ -461,6 +461,9 @@ def main(argv=None, hooks=None):
             with torch.no_grad(), torch.cuda.stream(streams[l]):
                 yield
                 streams[l].synchronize()
+    if on_gpu:
+        from camc2v_amd import ops as _ops
+        _ops.set_streams_in_flight(lanes)      # planner hint, read when the graphs are captured
     elapsed, _, out, ranks_seen = timed_clips(one_clip, args.steps, args.warmup, dist, sync, gather_latents(dist, world), lanes, lane_ctx)
     dev_ms = None
     if on_gpu and lanes == 1:
@@ -477,6 +480,7 @@ def main(argv=None, hooks=None):
         if first_ms:
             line["config"]["first_clip_ms"] = first_ms["v"]    # includes packing, graph capture (a new signature) and caches
         if world == 1 and extras and lanes > 1:      # the same clips one at a time (one stream), for comparison
+            _ops.set_streams_in_flight(1)
             run_clip(model, *sets[0], use_graph)         # this (the default) stream has no graphs yet: capture them untimed
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -53,6 +53,7 @@ class CcvAttn(C.Structure):
 # name -> (restype, argtypes); every symbol include/ccv.h declares
 SIGNATURES = {
     "ccv_version": (i32, []),
+    "ccv_set_streams_in_flight": (i32, [i32]),
     "ccv_last_error": (C.c_char_p, []),
     "ccv_gemm": (i32, [C.POINTER(CcvGemm), vp]),
     "ccv_gemm_ws_bytes": (i64, [C.POINTER(CcvGemm)]),

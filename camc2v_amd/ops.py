@@ -45,6 +45,11 @@ def _rows(t):
 # ---------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------
+def set_streams_in_flight(n):
+    """Planner hint: how many independent launch streams the caller keeps busy (see include/ccv.h).  Returns the previous value."""
+    return lib().ccv_set_streams_in_flight(int(n))
+
+
 def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
          residual=None, act=ACT_NONE, geglu=False, out_f32=False, out=None, gather=GATHER_LINEAR,
          conv=None, tconv=None, seg_rows=None, alpha=1.0, debug_ws=None):

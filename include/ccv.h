@@ -42,6 +42,11 @@ enum {
 };
 
 int ccv_version(void);
+/* Scheduling hint (the one process-wide setting of the library): how many independent launch streams the caller keeps busy at
+ * a time (1 = default).  With two or more, ccv_gemm's planner takes the larger tile already at one workgroup per CU instead of
+ * 1.5 (the other stream's kernels fill the rest of the chip): measured on MI355X +2 % frames/s with two clips in flight, -2 %
+ * with one.  Read when a launch is planned, so set it before capturing graphs.  Returns the previous value. */
+int ccv_set_streams_in_flight(int32_t n);
 const char* ccv_last_error(void);
 
 /* ------------------------------------------------------------------------------------

@@ -60,6 +60,12 @@ def test_argument_errors_are_reported_not_thrown(built):
     assert rc == -1 and b"null" in built.lib().ccv_last_error()
 
 
+def test_streams_in_flight_hint_round_trips(built):
+    assert built.lib().ccv_set_streams_in_flight(2) == 1       # default: one launch stream
+    assert built.lib().ccv_set_streams_in_flight(0) == 2       # clamped to >= 1
+    assert built.lib().ccv_set_streams_in_flight(1) == 1
+
+
 def test_product_path_refuses_cpu_tensors(built):
     from camc2v_amd import ops
     from camc2v_amd.lib import CcvError
