@@ -893,13 +893,17 @@ inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
 // alone (the 8x8 / 4x4 latent layers stream 10-60 MB of weights through a few dozen workgroups otherwise).
 // Fitted to tools/gemm_tune.py on MI355X: aim at ~2.5 workgroups per CU, keep >= 20 slabs of 64 per split, and
 // do not split when the fp32 partials (split * M * N * 4 bytes, written and re-read) outweigh the gain.
+inline long split_scale_pct() {   // tuning aid: CCV_GEMM_SPLITSCALE (percent) scales the workgroup counts split-K aims at
+    const int v = tune_env("CCV_GEMM_SPLITSCALE");
+    return v > 0 ? v : 100;
+}
 inline int choose_split(const CcvGemm& p) {
     int mt, nt;
     choose_tile(p, mt, nt);
     const long tiles = (long)((p.M + 32 * mt - 1) / (32 * mt)) * ((p.N + 32 * nt - 1) / (32 * nt));
     const int nslab = p.taps * (p.K / BK);
     if ((long)p.M * p.N > (4l << 20) || tiles >= 512) return 1;
-    long s = 640 / tiles;
+    long s = 640 * split_scale_pct() / 100 / tiles;
     if (s > nslab / 20) s = nslab / 20;
     if (s > 16) s = 16;
     return s < 2 ? 1 : (int)s;
@@ -1042,9 +1046,9 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     constexpr int r160 = 2;   // 4-stage 128x160 tile (the 2-stage instance, index 6, measured equal in-model)
     if (p.taps == 3) return tiles2 >= 512 ? ring(r160, 1) : family();
     // long-K 3x3 convolutions: 128x320 tiles, two workgroups per CU, split-K up to ~512 workgroups
-    if (ring_fits(p, 5) && nslab >= 256 && tiles0 >= 64) return ring(5, (int)(tiles0 >= 512 ? 1 : 512 / tiles0));
+    if (ring_fits(p, 5) && nslab >= 256 && tiles0 >= 64) return ring(5, (int)(tiles0 >= 512 ? 1 : 512 * split_scale_pct() / 100 / tiles0));
     if (tiles2 >= 512) return ring(r160, 1);
-    int sp = (int)(256 / tiles2);
+    int sp = (int)(256 * split_scale_pct() / 100 / tiles2);
     if (sp < 1) sp = 1;
     if (tiles2 >= 256 && nslab / sp >= 180) sp *= 2;
     return ring(r160, sp);
