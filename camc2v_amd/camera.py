@@ -11,7 +11,7 @@ Reference anchors: model/base.py:176-199 (get_relative_pose), model/camcontexti2
 """
 import torch
 
-from . import ops
+from . import ops, rng
 
 
 def relative_c2w(w2c, cond_frame_index, trace_scale_factor=1.0):
@@ -34,7 +34,7 @@ def pairwise_fundamental(K, rel_c2w, perturb_zero_translation=True, generator=No
     R, t = pairs[..., :3, :3], pairs[..., :3, 3:4]
     if perturb_zero_translation:
         if noise is None:
-            noise = torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=generator)
+            noise = torch.randn(t.shape, device=t.device, dtype=t.dtype, generator=generator) if generator is not None else rng.randn(t.shape, device=t.device, dtype=t.dtype)
         zero = (t.abs() < 1e-6).all(dim=-2, keepdim=True)
         t = torch.where(zero, noise.to(t) * 1e-6, t)
     E = torch.cross(t.expand_as(R), R, dim=-2)

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import rng
 from .config import instantiate_from_config
 from .lib import CcvError
 from .sampler import DDIMSampler, make_beta_schedule
@@ -76,7 +77,7 @@ class LatentDiffusionCore(nn.Module):
         return self.betas.device
 
     def q_sample(self, x_start, t, noise=None):
-        noise = torch.randn_like(x_start) if noise is None else noise
+        noise = rng.randn_like(x_start) if noise is None else noise
         shape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
         return (self.sqrt_alphas_cumprod[t].reshape(shape) * x_start
                 + self.sqrt_one_minus_alphas_cumprod[t].reshape(shape) * noise)

@@ -2,7 +2,7 @@
 PyTorch-Lightning (reference flow: CamContextI2V/02_generate_videos.py:197-355 -> main/trainer.py:80,146-194 -> ImageLogger
 (main/callbacks.py:163-196, 238-245) -> model.log_images -> utils/save_video.py:65-157).
 
-    python generate.py <eval_config.yaml> [--out DIR] [--num-samples N] [--synthetic-data] [--random-init] [--no-graph]
+    python generate.py <eval_config.yaml> [--out DIR] [--num-samples N] [--synthetic-data] [--random-init] [--no-graph] [--lanes L]
 
 What is honoured from the yaml: ``model`` (target / params / pretrained_checkpoint), ``data.params.{batch_size, test,
 test_max_n_samples}``, ``lightning.callbacks.batch_logger.params.{log_images_kwargs, test_directory}``.  One process per GPU
@@ -12,6 +12,7 @@ writes its own samples (``log_all_gpus: True`` in the reference's eval config); 
 import argparse
 import logging
 import os
+import threading
 import time
 
 import torch
@@ -69,7 +70,7 @@ def build_dataset(cfg, synthetic=False, num_samples=None):
     return ds, int(dcfg.get("batch_size", 1)), int(n)
 
 
-def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None):
+def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None, lanes=1):
     """Returns the list of sample directories written by this rank."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if device is None:
@@ -83,12 +84,51 @@ def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=F
     save_dir = out_dir or logger.get("test_directory") or os.path.join("results", "test")
     os.makedirs(save_dir, exist_ok=True)
     idx = list(range(min(n, len(ds))))[rank::world]
+    starts = list(range(0, len(idx), batch_size))
     written, t0 = [], time.perf_counter()
-    for s in range(0, len(idx), batch_size):
+
+    def one_batch(s):
         batch = collate([ds[i] for i in idx[s:s + batch_size]])
         logs = model.log_images(batch, split="test", use_graph=use_graph, **kw)
         logs = prepare_to_log(logs, -1, True)
-        written += log_evaluation(logs, save_dir, save_fps=7, rescale=True, print_out=(rank == 0))
+        return log_evaluation(logs, save_dir, save_fps=7, rescale=True, print_out=(rank == 0))
+
+    lanes = max(1, min(int(lanes), len(starts)))
+    if lanes == 1:
+        for s in starts:
+            written += one_batch(s)
+    else:
+        # `lanes` batches in flight: one host thread + HIP stream each (own hipGraphs and static buffers per stream, shared
+        # weights); the second batch fills the CUs the first one's small-latent layers leave idle
+        from . import ops
+        ops.set_streams_in_flight(lanes)
+        lock, nxt, done, errors = threading.Lock(), [0], {}, []
+
+        def lane(l, stream):
+            try:
+                torch.cuda.set_device(device)
+                with torch.no_grad(), torch.cuda.stream(stream):
+                    while True:
+                        with lock:
+                            j = nxt[0]
+                            nxt[0] += 1
+                        if j >= len(starts):
+                            break
+                        done[j] = one_batch(starts[j])
+                    stream.synchronize()
+            except BaseException as e:      # re-raised below, on the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=lane, args=(l, torch.cuda.Stream(device))) for l in range(lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        ops.set_streams_in_flight(1)
+        if errors:
+            raise errors[0]
+        for j in sorted(done):
+            written += done[j]
     dt = time.perf_counter() - t0
     log.info("[rank %d] %d clips in %.1f s -> %s", rank, len(written), dt, save_dir)
     return written
@@ -102,10 +142,11 @@ def main(argv=None):
     ap.add_argument("--synthetic-data", action="store_true", help="iterate synthetic clips even if the dataset directory exists")
     ap.add_argument("--random-init", action="store_true", help="sample from seeded random weights when the checkpoint is absent")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (host thread + HIP stream each)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s")
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
-    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph)
+    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph, lanes=args.lanes)
     print(f"wrote {len(written)} sample directories")
     return 0

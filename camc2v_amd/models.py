@@ -11,7 +11,7 @@ the matching checkpoint slices load.  The OpenCLIP encoders need third-party cod
 """
 import torch
 
-from . import camera
+from . import camera, rng
 from .config import instantiate_from_config
 from .diffusion import LatentDiffusionCore
 from .lib import CcvError
@@ -138,7 +138,7 @@ class DynamiCrafter(LatentDiffusionCore):
             cond_frame_index = torch.zeros(b, device=device, dtype=torch.long)
             rand = self.rand_cond_frame if rand_cond_frame is None else rand_cond_frame
             if rand:
-                cond_frame_index = torch.randint(0, tl, (b,), device=device)
+                cond_frame_index = rng.randint(0, tl, (b,), device=device)
         depth_scale = torch.ones((b,), device=device)
         camera_kwargs = {}
         if enable_camera_condition:

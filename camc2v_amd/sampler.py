@@ -13,12 +13,10 @@ schedule arithmetic as the reference sampler (``lvdm/models/samplers/ddim.py:10-
   * the camera dict is shared with the unconditional branch by reference (the reference
     deep-copies the 268 MB mask every step, ddim.py:258-260).
 """
-import threading
-
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, rng
 from .lib import CcvError
 
 
@@ -66,8 +64,9 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     return sig.float().numpy(), a.numpy(), a_prev.float().numpy()
 
 
-# one capture (and weight packing) at a time: captures of different lanes come from different host threads
-_CAPTURE_LOCK = threading.RLock()
+# one capture at a time (captures of different lanes come from different host threads), and no default-generator draw on
+# another thread meanwhile: see rng.py
+_CAPTURE_LOCK = rng.LOCK
 
 
 def _unet_of(model):
@@ -271,7 +270,7 @@ class _GraphedClip:
         self.coef.copy_(coef_row)
         if self.noise is not None:
             if noise is None:
-                self.noise.normal_()
+                rng.normal_(self.noise)
             else:
                 self.noise.copy_(noise)
         self.graph.replay()
@@ -345,7 +344,7 @@ class DDIMSampler(object):
                 raise NotImplementedError(f"{flag} belongs to the autoregressive demo path, not to the hot path")
         device = self.model.betas.device
         b = shape[0]
-        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device).float().contiguous()
+        img = rng.randn(shape, device=device) if x_T is None else x_T.to(device).float().contiguous()
         steps = self.ddim_timesteps
         total = steps.shape[0]
         intermediates = {"x_inter": [img], "pred_x0": [img]}
@@ -435,7 +434,7 @@ class DDIMSampler(object):
                                            t.contiguous() if scheduler == "cosine" else None)
         if noise is None and coef is None and float(self.ddim_sigmas[index]) != 0.0:
             shape = (1, *x.shape[1:]) if repeat_noise else x.shape
-            noise = torch.randn(shape, device=x.device).expand(x.shape).contiguous()
+            noise = rng.randn(shape, device=x.device).expand(x.shape).contiguous()
         if noise is not None and temperature != 1.0:
             noise = noise * temperature
         x_prev, pred_x0 = ops.ddim_cfg_step(x, e_c.float().contiguous(), None if e_uc is None else e_uc.float().contiguous(),

@@ -15,7 +15,7 @@ GEMM whose "activation" operand is the value weight.
 import torch
 import torch.nn as nn
 
-from . import ops, pack
+from . import ops, pack, rng
 from .lib import CcvError
 from .unet import _Prepared, _dev_f32
 
@@ -307,7 +307,7 @@ class DiagonalGaussianDistribution:
 
     def sample(self, noise=None):
         if noise is None:
-            noise = torch.randn_like(self.mean)
+            noise = rng.randn_like(self.mean)
         return self.mean + self.std * noise.to(self.mean.device)
 
     def mode(self):
