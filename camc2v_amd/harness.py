@@ -26,9 +26,12 @@ from .video_io import log_evaluation, prepare_to_log
 log = logging.getLogger("mainlogger")
 
 
-def build_model(cfg, device, random_init=False, report=None):
+def build_model(cfg, device, random_init=False, report=None, encoders=False):
+    """``encoders``: also build the OpenCLIP text / image embedders (their weights are the ``cond_stage_model.*`` / ``embedder.*``
+    slices of the checkpoint); needed when the batches carry captions and frames only -- the synthetic dataset carries the
+    embedders' outputs."""
     model = instantiate_from_config(cfg["model"])
-    model.build_feeders()
+    model.build_feeders(encoders=encoders)
     ckpt = cfg["model"].get("pretrained_checkpoint")
     if ckpt and os.path.exists(ckpt):
         load_checkpoints(model, cfg["model"], report)
@@ -70,15 +73,15 @@ def build_dataset(cfg, synthetic=False, num_samples=None):
     return ds, int(dcfg.get("batch_size", 1)), int(n)
 
 
-def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None, lanes=1):
+def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None, lanes=1, encoders=None):
     """Returns the list of sample directories written by this rank."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if device is None:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.set_grad_enabled(False)
-    model = build_model(cfg, device, random_init)
     ds, batch_size, n = build_dataset(cfg, synthetic, num_samples)
+    model = build_model(cfg, device, random_init, encoders=encoders if encoders is not None else not isinstance(ds, SyntheticRealEstate))
     logger = cfg.get("lightning", {}).get("callbacks", {}).get("batch_logger", {}).get("params", {})
     kw = dict(logger.get("log_images_kwargs") or {})
     save_dir = out_dir or logger.get("test_directory") or os.path.join("results", "test")
@@ -142,11 +145,12 @@ def main(argv=None):
     ap.add_argument("--synthetic-data", action="store_true", help="iterate synthetic clips even if the dataset directory exists")
     ap.add_argument("--random-init", action="store_true", help="sample from seeded random weights when the checkpoint is absent")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--encoders", action="store_true", help="build the OpenCLIP embedders even for the synthetic dataset")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (host thread + HIP stream each)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s")
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
-    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph, lanes=args.lanes)
+    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph, lanes=args.lanes, encoders=True if args.encoders else None)
     print(f"wrote {len(written)} sample directories")
     return 0

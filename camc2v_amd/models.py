@@ -42,11 +42,16 @@ class DynamiCrafter(LatentDiffusionCore):
     _FEEDER_ATTRS = {"first_stage_config": "first_stage_model", "image_proj_stage_config": "image_proj_model",
                      "pose_encoder_config": "pose_encoder", "multi_latent_adaptor": "multi_cond_latent_adaptor"}
 
-    def build_feeders(self, which=None):
+    _ENCODER_ATTRS = {"cond_stage_config": "cond_stage_model", "img_cond_stage_config": "embedder"}
+
+    def build_feeders(self, which=None, encoders=False):
         """Instantiate the once-per-clip feeders built on the HIP kernels from the kept yaml configs (all of them, or the
-        config keys in ``which``); returns the list of attribute names created."""
+        config keys in ``which``); returns the list of attribute names created.  ``encoders=True`` also builds the OpenCLIP
+        text / image embedders (``cond_stage_model`` / ``embedder``: ~1 B parameters whose weights come from the checkpoint);
+        without them the batch has to carry their outputs (``caption_emb``, ``image_clip_tokens``)."""
         made = []
-        for key, attr in self._FEEDER_ATTRS.items():
+        attrs = dict(self._FEEDER_ATTRS, **(self._ENCODER_ATTRS if encoders else {}))
+        for key, attr in attrs.items():
             if key in self.feeder_configs and (which is None or key in which) and not hasattr(self, attr):
                 mod = instantiate_from_config(self.feeder_configs[key]).eval()
                 for p_ in mod.parameters():
