@@ -318,9 +318,9 @@ def skipped_flops(inputs):
     return epi_clip, kv_ref - kv_here
 
 
-def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None, lanes=1):
+def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None, lanes=1, sharded=False):
     from camc2v_amd import configs
-    clips = steps * world
+    clips = steps if sharded else steps * world          # frame-sharded: the ranks sample each clip TOGETHER
     tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
     per_clip_s = (dev_ms / 1e3 / steps) if dev_ms is not None else elapsed / steps
     achieved = tf_per_clip / per_clip_s  # one GPU's rate: algorithmic TFLOP of a clip / its device time
@@ -352,13 +352,13 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
         "metric": "denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
         "value": 16.0 * clips / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, "
                                "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights; every clip "
                                "has its own conditioning tensors (per-clip prologue inside the timed region); every sampling call "
                                "is ONE clip (UNet batch 2 under CFG) -- clips_in_flight_per_gpu independent calls run on "
                                "their own HIP streams at a time",
-                   "clips_per_gpu": 1, "clips_in_flight_per_gpu": lanes, "parallelism": f"clip-dp{world}",
+                   "clips_per_gpu": 1, "clips_in_flight_per_gpu": lanes, "parallelism": f"frame-shard{world}" if sharded else f"clip-dp{world}",
                    "launch": "hipGraph" if use_graph else "eager"},
         "roofline": roof,
     }
@@ -395,6 +395,8 @@ def main(argv=None, hooks=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--same-conditioning", action="store_true", help="every clip reuses clip 0's tensors (round-1 behaviour)")
     ap.add_argument("--lanes", type=int, default=2, help="independent clips in flight per GPU (one host thread + HIP stream + hipGraph set each)")
+    ap.add_argument("--frame-shard", action="store_true", help="single-clip latency mode: the N ranks sample EVERY clip together, its 16 frames "
+                    "sharded over them (camc2v_amd/parallel.py; eager, strong scaling); default is one independent clip stream per rank")
     ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
     args = ap.parse_args(argv)
     hooks = hooks or {}
@@ -434,8 +436,13 @@ def main(argv=None, hooks=None):
     make_inputs = hooks.get("synthetic_inputs", synthetic_inputs)
     run_clip = hooks.get("sample_clip", sample_clip)
     n_sets = 1 if args.same_conditioning else args.steps + args.warmup
-    sets = [make_inputs(model, device, rank=rank, clip=i) for i in range(n_sets)]
-    use_graph = not args.no_graph
+    sharded = bool(args.frame_shard and world > 1)
+    sets = [make_inputs(model, device, rank=0 if sharded else rank, clip=i) for i in range(n_sets)]     # sharded: all ranks work on the same clips
+    use_graph = not args.no_graph and not sharded
+    if sharded:
+        args.lanes = 1
+        if on_gpu:
+            model.model.diffusion_model.enable_frame_sharding()
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if on_gpu else None
     first_ms = {}
@@ -476,7 +483,7 @@ def main(argv=None, hooks=None):
         extras = on_gpu and hooks.get("extras", True) and not args.clips_only
         dom = dominant_kernel(model, device, sets[0]) if extras else None
         skipped = skipped_flops(sets[0]) if extras else None
-        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen, lanes)
+        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen, lanes, sharded)
         if first_ms:
             line["config"]["first_clip_ms"] = first_ms["v"]    # includes packing, graph capture (a new signature) and caches
         if world == 1 and extras and lanes > 1:      # the same clips one at a time (one stream), for comparison

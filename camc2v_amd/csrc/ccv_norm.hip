@@ -418,6 +418,43 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     return CCV_OK;
 }
 
+// The two halves of ccv_groupnorm as separate calls, for statistics that span more rows than this process holds (a clip whose
+// frames are sharded over GPUs: the caller sums the per-chunk partials, all-reduces them and hands the totals back).
+extern "C" int32_t ccv_groupnorm_chunks(int32_t instances, int32_t rows_per_instance, int32_t C) {
+    if (instances <= 0 || rows_per_instance <= 0 || C <= 0 || C % 64 != 0) return 0;
+    return gn_chunks(instances, rows_per_instance, C);
+}
+
+extern "C" int ccv_groupnorm_stats(const void* x, int32_t x_f32, int32_t instances, int32_t rows_per_instance, int32_t C, void* ws, void* stream) {
+    CCV_REQUIRE(x && ws, CCV_EINVAL, "ccv_groupnorm_stats: null pointer");
+    CCV_REQUIRE(instances > 0 && instances <= 65535 && rows_per_instance > 0, CCV_EINVAL, "ccv_groupnorm_stats: bad sizes");
+    CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm_stats: C=%d must be a multiple of 64 and <= 4096", C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
+    if (x_f32)
+        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(gn_threads(C)), 0, st, x, static_cast<float*>(ws), rows_per_instance, C);
+    else
+        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(gn_threads(C)), 0, st, x, static_cast<float*>(ws), rows_per_instance, C);
+    CCV_LAUNCH_CHECK("ccv_groupnorm_stats");
+    return CCV_OK;
+}
+
+extern "C" int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
+                                   int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* ws, float inv_count, void* stream) {
+    CCV_REQUIRE(x && y && gamma && beta && ws, CCV_EINVAL, "ccv_groupnorm_apply: null pointer");
+    CCV_REQUIRE(instances > 0 && instances <= 65535 && rows_per_instance > 0 && inv_count > 0.f, CCV_EINVAL, "ccv_groupnorm_apply: bad sizes");
+    CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm_apply: C=%d must be a multiple of 64 and <= 4096", C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
+    const float* partial = static_cast<const float*>(ws);
+    if (x_f32)
+        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
+    else
+        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
+    CCV_LAUNCH_CHECK("ccv_groupnorm_apply");
+    return CCV_OK;
+}
+
 extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, const float* beta,
                              int32_t rows, int32_t C, float eps, const uint16_t* addend, int32_t addend_rows, uint16_t* y2, void* stream) {
     CCV_REQUIRE(x && y && gamma && beta, CCV_EINVAL, "ccv_layernorm: null pointer");

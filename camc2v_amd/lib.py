@@ -60,6 +60,9 @@ SIGNATURES = {
     "ccv_gemm_plan": (i32, [C.POINTER(CcvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
+    "ccv_groupnorm_chunks": (i32, [i32, i32, i32]),
+    "ccv_groupnorm_stats": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "ccv_groupnorm_apply": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, f32, vp]),
     "ccv_groupnorm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
     "ccv_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp, vp]),
     "ccv_pack_nchw_to_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),

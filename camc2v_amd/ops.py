@@ -264,6 +264,31 @@ def groupnorm(x, gamma, beta, *, instances, eps, silu):
     return y
 
 
+def groupnorm_sharded(x, gamma, beta, *, instances, eps, silu, reduce_sums, total_rows_per_instance):
+    """GroupNorm whose statistics span rows held by several processes: x [rows, C] are THIS process's rows of every instance;
+    ``reduce_sums(t)`` sums the fp32 tensor t [instances, 64] in place over the processes (an all_reduce);
+    ``total_rows_per_instance`` = rows of an instance over all processes.  Same kernels as ``groupnorm``, split in two."""
+    _dev(x, gamma, beta)
+    rows, Cc = _rows(x)
+    if rows % instances:
+        raise CcvError("groupnorm_sharded: rows not divisible by instances")
+    rpi = rows // instances
+    nchunk = lib().ccv_groupnorm_chunks(instances, rpi, Cc)
+    ws = torch.empty(lib().ccv_groupnorm_ws_bytes(instances, Cc) // 4, dtype=F32, device=x.device)
+    xf = int(x.dtype == F32)
+    check(lib().ccv_groupnorm_stats(_ptr(x), xf, instances, rpi, Cc, _ptr(ws), _stream()), "ccv_groupnorm_stats")
+    part = ws[:instances * nchunk * 64].view(instances, nchunk, 64)
+    sums = part.sum(1)
+    reduce_sums(sums)
+    part.zero_()
+    part[:, 0] = sums
+    y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    inv_count = 1.0 / (float(total_rows_per_instance) * (Cc // 32))
+    check(lib().ccv_groupnorm_apply(_ptr(x), xf, _ptr(y), _ptr(gamma), _ptr(beta), instances, rpi, Cc, eps, int(silu), _ptr(ws), inv_count,
+                                    _stream()), "ccv_groupnorm_apply")
+    return y
+
+
 def layernorm(x, gamma, beta, *, eps=1e-5, addend=None, out2=None):
     """x [rows, C] fp32 -> bf16 (and y + addend[r % addend_rows] when addend is given; `out2`: where that second output goes)."""
     _dev(x, gamma, beta, addend)

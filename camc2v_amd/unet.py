@@ -26,7 +26,7 @@ from collections import OrderedDict, namedtuple
 import torch
 import torch.nn as nn
 
-from . import ops, pack
+from . import ops, pack, parallel
 from .lib import CcvError
 
 Geom = namedtuple("Geom", "b t h w")
@@ -49,6 +49,16 @@ def _dev_f32(p):
 
 
 _PACK_LOCK = threading.RLock()
+
+
+def _clip_groupnorm(x, gamma, beta, g, eps, silu):
+    """GroupNorm whose statistics run over a whole clip (t, h, w): one instance per sample -- over the frames of EVERY rank when
+    the clip's frames are sharded (parallel.FrameCtx)."""
+    fc = parallel.current()
+    if fc is None:
+        return ops.groupnorm(x, gamma, beta, instances=g.b, eps=eps, silu=silu)
+    return ops.groupnorm_sharded(x, gamma, beta, instances=g.b, eps=eps, silu=silu, reduce_sums=fc.shard.all_reduce_sum,
+                                 total_rows_per_instance=fc.T * g.h * g.w)
 
 
 class _Prepared:
@@ -148,6 +158,13 @@ class CrossAttention(nn.Module, _Prepared):
         ld = 3 * C
         s = (g.t * hw * ld, ld, hw * ld)
         o = torch.empty((n.shape[0], C), dtype=ops.BF16, device=n.device) if out is None else out
+        fc = parallel.current()
+        if fc is not None:     # frames sharded over ranks: this rank's queries against every rank's keys / values
+            kv = fc.gather_frames(qkv[:, C:].contiguous(), g.b, hw)                    # [(b T hw), 2C]
+            sk = (fc.T * hw * 2 * C, 2 * C, hw * 2 * C)
+            ops.attention(qkv, kv, kv[:, C:], B=g.b * hw, inner=hw, H=H, Lq=g.t, Lk=fc.T, q_str=s, k_str=sk, v_str=sk, out=o,
+                          o_str=(g.t * hw * C, C, hw * C), scale=self.scale)
+            return o
         ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b * hw, inner=hw, H=H, Lq=g.t, Lk=g.t,
                       q_str=s, k_str=s, v_str=s, out=o, o_str=(g.t * hw * C, C, hw * C), scale=self.scale)
         return o
@@ -177,7 +194,10 @@ class CrossAttention(nn.Module, _Prepared):
             kw = {}
             if kv_i is not None:
                 if per_frame:   # 16 tokens of its own for every frame (reference openaimodel3d.py:575-579)
-                    st = (g.t * li * 2 * C, li * 2 * C, 2 * C)
+                    fc = parallel.current()     # frame-sharded: this rank's frames start at f0 of the clip's T
+                    t_all, f0 = (fc.T, fc.f0) if fc is not None else (g.t, 0)
+                    st = (t_all * li * 2 * C, li * 2 * C, 2 * C)
+                    kv_i = kv_i[f0 * li:] if f0 else kv_i
                 else:           # the same image tokens for every frame (:580-581)
                     st = (li * 2 * C, 0, 2 * C)
                 kw = dict(k2=kv_i, v2=kv_i[:, C:], k2_str=st, v2_str=st, Lk2=li, gate2=pk["gate"])
@@ -323,6 +343,14 @@ class Epipolar(nn.Module, _Prepared):
             if perm is not None and perm != (g.h * g.w, g.w):
                 raise CcvError(f"epipolar mask was packed for frames {perm}, feature map is {g.h}x{g.w}")
             kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm, wave_bits=wbits, group_order=order)
+        fc = parallel.current()
+        if fc is not None:     # frames sharded over ranks: local queries (and their mask rows, prepared in UNetModel.forward)
+            kv = fc.gather_frames(qkv[:, C:].contiguous(), g.b, g.h * g.w)           # against all T*h*w keys / values
+            La = fc.T * g.h * g.w
+            if out is not None:
+                kw.update(out=out, o_str=(L * C, 0, C))
+            return ops.attention(qkv, kv, kv[:, C:], B=g.b, inner=1, H=H, Lq=L, Lk=La, q_str=s, k_str=(La * 2 * C, 0, 2 * C),
+                                 v_str=(La * 2 * C, 0, 2 * C), kreg=pk.get("kreg"), vreg=pk.get("vreg"), scale=self.epipolar_attn.scale, **kw)
         if FP8_EPIPOLAR and kw and kw.get("wave_bits") is not None and L >= FP8_EPIPOLAR_MIN_TOKENS:
             # BASELINE.json configs[4]: e4m3 q / K / V / P with fp32 softmax (off by default: measured in DESIGN.md section 4)
             return ops.attention_sparse_fp8(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, H=H, L=L, q_str=s, k_str=s, v_str=s, mask_bits=kw["mask_bits"],
@@ -489,7 +517,7 @@ class TemporalTransformer(nn.Module, _Prepared):
 
     def forward_rows(self, x, g, cam):
         pk = self._pk()
-        n = ops.groupnorm(x, pk["gn_g"], pk["gn_b"], instances=g.b, eps=self.norm.eps, silu=False)
+        n = _clip_groupnorm(x, pk["gn_g"], pk["gn_b"], g, self.norm.eps, False)
         s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_f32=True)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
@@ -575,9 +603,18 @@ class TemporalConvBlock(nn.Module, _Prepared):
         pk = self._pk()
         C = self.in_channels
         h = x
+        fc = parallel.current()
         for i in range(4):
-            z = ops.groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], instances=g.b, eps=1e-5, silu=True)
+            z = _clip_groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], g, 1e-5, True)
             last = i == 3
+            if fc is not None:     # frames sharded over ranks: the neighbours' edge frames in front of / behind the local ones
+                hw = g.h * g.w
+                ze = fc.with_halo(z, g.b, hw)
+                he = ops.gemm(ze, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t + 2, hw), out_f32=last)
+                h = fc.inner(he, g.b, hw)
+                if last:
+                    h = h + x
+                continue
             h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3,
                          tconv=(g.t, g.h * g.w), residual=x if last else None, out_f32=last)
         return h
@@ -935,6 +972,39 @@ class UNetModel(nn.Module, _Prepared):
                 masks[k] = (mp[0], mp[1], m.shape[0], perm, mp.wave_bits, mp.group_order)
         return dict(rows=rows, masks=masks, add_type=camera_condition.get("add_type"))
 
+    def _local_camera_inputs(self, cam, fc, H, W):
+        """Frame-sharded forward: this rank's Pluecker rows and the mask rows of its queries (against all T*h*w keys)."""
+        rows = None
+        if cam["rows"] is not None:
+            rows = []
+            for lvl, r in enumerate(cam["rows"]):
+                hw = max(H >> lvl, 1) * max(W >> lvl, 1)
+                nb = r.shape[0] // (fc.T * hw)
+                rows.append(self._inputs.get(("pluker_local", fc.f0, fc.t_loc), r, lambda r=r, nb=nb, hw=hw: fc.local_frames(r, nb, hw)))
+        masks = {}
+        for k, (bits, flags, nb, perm, wbits, order) in cam["masks"].items():
+            L = bits.shape[1]
+            hw = L // fc.T
+
+            def make(bits=bits, L=L, hw=hw):
+                loc = bits[:, fc.f0 * hw:(fc.f0 + fc.t_loc) * hw]
+                shifts = torch.arange(32, device=bits.device, dtype=torch.int32)
+                dense = ((loc.unsqueeze(-1) >> shifts) & 1).bool().reshape(loc.shape[0], loc.shape[1], -1)[:, :, :L]
+                return ops.pack_mask(dense.contiguous())      # rows / bit columns stay in the order they were packed in (`perm`)
+            mp = self._inputs.get(("mask_local", fc.f0, fc.t_loc), bits, make)
+            masks[k] = (mp[0], mp[1], nb, perm, mp.wave_bits, mp.group_order)
+        return dict(rows=rows, masks=masks, add_type=cam["add_type"])
+
+    def enable_frame_sharding(self, group=None):
+        """Shard the frames of every clip over the ranks of ``group`` (default: the world); see parallel.py.  hipGraph capture of
+        the sampling step is not available in this mode (the exchanges are torch.distributed calls)."""
+        self.__dict__["frame_shard"] = parallel.FrameShard(group)
+        return self
+
+    def disable_frame_sharding(self):
+        self.__dict__.pop("frame_shard", None)
+        return self
+
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, x, timesteps, context=None, features_adapter=None, fs=None, camera_condition=None,
                 cfg_shared_input=False, **kwargs):
@@ -952,17 +1022,28 @@ class UNetModel(nn.Module, _Prepared):
             raise NotImplementedError("features_adapter is not used on the generation path")
         if not x.is_cuda:
             raise CcvError("UNetModel.forward: the product path runs on the GPU only (see oracle/ for the CPU restatement)")
+        shard = self.__dict__.get("frame_shard")
+        if shard is not None and parallel.current() is None:
+            # frames of every clip sharded over the ranks of a process group (parallel.py): run this rank's frames, gather the output
+            with parallel.FrameCtx(shard, x.shape[2]) as fc:
+                xl = x[:, :, fc.f0:fc.f0 + fc.t_loc].contiguous()
+                yl = self.forward(xl, timesteps, context, None, fs, camera_condition, cfg_shared_input, **kwargs)
+                return torch.cat(shard.all_gather(yl), 2)
         pk = self._pk()
         b0, _, t, H, W = x.shape
         shared = bool(cfg_shared_input)
         b = 2 * b0 if shared else b0
         g = Geom(b0, t, H, W)          # geometry of the (possibly shared) prefix
         mc = self.model_channels
+        fc = parallel.current()
+        t_all = fc.T if fc is not None else t     # frames of the whole clip (t = this rank's share when sharded)
 
-        nclips, ctx_iter = self._context_groups(context, t)
+        nclips, ctx_iter = self._context_groups(context, t_all)
         if nclips != b:
             raise CcvError(f"context covers {nclips} samples, x has {b}")
-        cam = self._camera_inputs(camera_condition, b, t, H, W)
+        cam = self._camera_inputs(camera_condition, b, t_all, H, W)
+        if fc is not None and cam is not None:
+            cam = self._local_camera_inputs(cam, fc, H, W)
         if self.__dict__.get("_inputs_only"):
             return torch.zeros((b, self.out_channels, t, H, W), dtype=torch.float32, device=x.device)
 

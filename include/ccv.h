@@ -198,6 +198,16 @@ int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const float* gamma,
                   int32_t instances, int32_t rows_per_instance, int32_t C, float eps, int32_t silu,
                   void* ws, void* stream);
 
+/* The two halves of ccv_groupnorm as separate calls, for statistics that span more rows than this process holds -- a clip whose
+ * frames are sharded over GPUs (GroupNorm over (t, h, w) in TemporalConvBlock / TemporalTransformer, openaimodel3d.py:255-266,
+ * attention.py:343): ccv_groupnorm_stats fills ws (the ccv_groupnorm workspace) with per-chunk (sum, sum of squares) partials
+ * laid out [instances][ccv_groupnorm_chunks(...)][32 groups][2]; the caller reduces them over chunks and ranks, writes the totals
+ * into chunk 0 (zeros elsewhere) and calls ccv_groupnorm_apply with inv_count = 1 / (elements per group over ALL ranks). */
+int32_t ccv_groupnorm_chunks(int32_t instances, int32_t rows_per_instance, int32_t C);
+int ccv_groupnorm_stats(const void* x, int32_t x_f32, int32_t instances, int32_t rows_per_instance, int32_t C, void* ws, void* stream);
+int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
+                        int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* ws, float inv_count, void* stream);
+
 /* LayerNorm over the last dim, fp32 in -> bf16 out; optional second output
  * y2[r] = y[r] + addend[r % addend_rows] (bf16 [addend_rows, C]) used for the Pluecker-feature add `normed_x + pluker_embedding_features`
  * (model/modules/modified_forwards.py:508-515).  Replaces nn.LayerNorm (attention.py:232-234).

@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, lanes=1, steps=3):
+def _worker(rank, world, port, out_dir, lanes=1, steps=3, extra=()):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     import bench
@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_dir, lanes=1, steps=3):
 
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        rc = bench.main(["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--lanes", str(lanes)],
+        rc = bench.main(["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--lanes", str(lanes), *extra],
                         hooks=dict(device=torch.device("cpu"), backend="gloo", build_model=lambda dev: None,
                                    synthetic_inputs=make_inputs, sample_clip=fake_clip))
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
@@ -87,6 +87,18 @@ def test_two_rank_bench_main_with_two_clips_in_flight(tmp_path):
     assert 50.0 - 5.0 <= line["ms_per_step"] <= 85.0
     assert line["value"] == pytest.approx(16.0 * 4 * 2 / (line["ms_per_step"] * 4 / 1e3))
     assert line["config"]["ranks_in_final_all_gather"] == 2
+
+
+def test_two_rank_bench_main_frame_sharded(tmp_path):
+    """--frame-shard: the ranks work on the SAME clips (rank 0's input sets), so the job's frames are those of K clips, not K x N
+    (strong scaling)."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), 1, 3, ("--frame-shard",)), nprocs=world, join=True)
+    r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(world)]
+    assert r[0]["rc"] == 0 and r[1]["rc"] == 0 and r[0]["clips"] == r[1]["clips"] == [0, 1, 2, 3, 4]
+    line = json.loads([ln for ln in r[0]["stdout"].splitlines() if ln.strip()][0])
+    assert line["scaling"] == "strong" and line["config"]["parallelism"] == "frame-shard2" and line["config"]["launch"] == "eager"
+    assert line["value"] == pytest.approx(16.0 * 3 / (line["ms_per_step"] * 3 / 1e3))
 
 
 def test_gpus_flag_must_match_the_launcher(monkeypatch):
