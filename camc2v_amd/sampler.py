@@ -176,7 +176,8 @@ class _GraphedClip:
     A new clip costs one copy of its conditioning (~0.1 GB) + one prologue replay; only a new *signature* (shapes,
     kwargs, weights generation) captures again.  Graphs are cached on the model."""
 
-    MAX_CACHED = 2
+    MAX_CACHED = 2      # signatures per stream
+    MAX_TOTAL = 6       # graph sets in all (streams x signatures)
 
     @staticmethod
     def _split(cond, kw):
@@ -203,10 +204,12 @@ class _GraphedClip:
                 cache.pop(k)
             hit = cache.get(key)
             if hit is None:
-                lanes = {k[4] for k in cache} | {lane}
-                while sum(1 for k in cache if k[4] == lane) >= cls.MAX_CACHED or len(cache) >= cls.MAX_CACHED * len(lanes):
-                    victim = next((k for k in cache if k[4] == lane), next(iter(cache)))
-                    cache.pop(victim)
+                # at most MAX_CACHED signatures per stream and MAX_TOTAL sets in all (a set pins its graphs' memory pool; streams
+                # that no longer exist would otherwise keep theirs for ever): oldest of this stream first, then oldest overall
+                while sum(1 for k in cache if k[4] == lane) >= cls.MAX_CACHED:
+                    cache.pop(next(k for k in cache if k[4] == lane))
+                while len(cache) >= cls.MAX_TOTAL:
+                    cache.pop(next(iter(cache)))
                 hit = cache[key] = cls(sampler, x, tree, stochastic)
         hit.sampler = sampler
         hit.load(tree)
