@@ -413,9 +413,14 @@ def main(argv=None, hooks=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     on_gpu = "device" not in hooks
+    # CCV_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- rehearses the N-rank code path on a one-GPU box (RCCL refuses two ranks
+    # on one device); the numbers of such a run mean nothing
+    rehearsal = on_gpu and os.environ.get("CCV_BENCH_REHEARSAL") == "1"
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        if rehearsal:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
@@ -426,7 +431,9 @@ def main(argv=None, hooks=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
-            if on_gpu:
+            if on_gpu and rehearsal:
+                dist.init_process_group("gloo")
+            elif on_gpu:
                 dist.init_process_group("nccl", device_id=device)
             else:
                 dist.init_process_group(hooks.get("backend", "gloo"), rank=rank, world_size=world)
