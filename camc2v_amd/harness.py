@@ -104,7 +104,7 @@ def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=F
         # `lanes` batches in flight: one host thread + HIP stream each (own hipGraphs and static buffers per stream, shared
         # weights); the second batch fills the CUs the first one's small-latent layers leave idle
         from . import ops
-        ops.set_streams_in_flight(lanes)
+        prev_hint = ops.set_streams_in_flight(lanes)
         lock, nxt, done, errors = threading.Lock(), [0], {}, []
 
         def lane(l, stream):
@@ -127,7 +127,7 @@ def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=F
             t.start()
         for t in threads:
             t.join()
-        ops.set_streams_in_flight(1)
+        ops.set_streams_in_flight(prev_hint)
         if errors:
             raise errors[0]
         for j in sorted(done):
