@@ -1045,8 +1045,10 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             const int slot = next_slot.fetch_add(1) & 63;   // successive launches use different counter rows; callers whose launches
                                                             // overlap on several streams pass their own zeroed queue_counters
             const long groups = (long)((p.Lq + 63) / 64) * p.H * p.B;
-            static const long per_cu = [] { const char* e = getenv("CCV_ATTN_SPARSE_WGS"); const int v = e ? atoi(e) : 2; return (long)(v >= 1 && v <= 2 ? v : 2); }();   // A/B aid
-            const long wgs = (groups + 3) / 4 < per_cu * n_cu ? (groups + 3) / 4 : per_cu * n_cu;
+            // persistent workgroups in percent of the CU count (A/B aid; 200 = two per CU = all the LDS)
+            static const long pct = [] { const char* e = getenv("CCV_ATTN_SPARSE_PCT"); const int v = e ? atoi(e) : 200; return (long)(v >= 50 && v <= 200 ? v : 200); }();
+            const long cap = pct * n_cu / 100;
+            const long wgs = (groups + 3) / 4 < cap ? (groups + 3) / 4 : cap;
             if (!p.queue_counters) hipLaunchKernelGGL(sparse_ctr_reset, dim3(1), dim3(64), 0, st, slot);
             static const int xcd_queues = [] { const char* e = getenv("CCV_ATTN_XCD"); return e ? atoi(e) : 0; }();   // 0 (default): one chip-wide queue; 1: per-XCD queues
             // (HW_REG_XCC_ID); 2: per-XCD queues with blockIdx & 7 as the label.  Measured on MI355X (profiles/r02_sparse_xcd_queues.txt):
