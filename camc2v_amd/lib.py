@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccv_hip.so")
+LIB_PATH = os.environ.get("CCV_HIP_LIB") or os.path.join(_HERE, "libccv_hip.so")    # CCV_HIP_LIB: another build of the library (A/B runs)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
