@@ -45,6 +45,28 @@ class FrameShard:
         return parts
 
 
+class CfgSplit:
+    """Classifier-free guidance over TWO ranks (SURVEY.md section 8e "CFG split"): rank 0 runs the conditional forward of every step,
+    rank 1 the unconditional one; one all_gather of the 256 KB noise prediction per step, after which both ranks run the guidance
+    + DDIM update on identical data.  ``model.cfg_split = CfgSplit(group)``; with ``use_graph=True`` each rank's forward is a
+    hipGraph and only the exchange and the two-launch update stay outside it."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise CcvError("CfgSplit needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world != 2:
+            raise CcvError(f"the CFG split is for exactly 2 ranks (conditional / unconditional), the group has {self.world}")
+
+    def exchange(self, mine):
+        """this rank's noise prediction -> (e_cond, e_uncond)"""
+        mine = mine.contiguous()
+        parts = [torch.empty_like(mine), torch.empty_like(mine)]
+        dist.all_gather(parts, mine, group=self.group)
+        return parts[0], parts[1]
+
+
 class FrameCtx:
     """One sharded forward: T frames in all, this rank holds [f0, f0 + t_loc)."""
 
@@ -91,4 +113,4 @@ class FrameCtx:
         return rows.reshape(nb, self.T, hw, C)[:, self.f0:self.f0 + self.t_loc].reshape(nb * self.t_loc * hw, C).contiguous()
 
 
-__all__ = ["FrameShard", "FrameCtx", "current"]
+__all__ = ["FrameShard", "FrameCtx", "CfgSplit", "current"]

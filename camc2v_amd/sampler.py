@@ -198,7 +198,8 @@ class _GraphedClip:
         # graphs (and their static conditioning buffers) belong to the stream they were captured on: a second clip in flight
         # on another stream (bench.py --lanes, one host thread per lane) gets its own set instead of sharing buffers
         lane = torch.cuda.current_stream(x.device).cuda_stream
-        key = (gen, tuple(x.shape), stochastic, _StaticTree.describe(tree), lane)
+        split = getattr(sampler.model, "cfg_split", None)
+        key = (gen, tuple(x.shape), stochastic, _StaticTree.describe(tree), lane, None if split is None else split.rank)
         with _CAPTURE_LOCK:
             for k in [k for k in cache if k[0] != gen]:      # graphs captured on weights that were since replaced
                 cache.pop(k)
@@ -232,8 +233,21 @@ class _GraphedClip:
         self.coef.copy_(sampler.ddim_coef[0])
         unet = _unet_of(sampler.model)
 
+        # CFG split over two ranks (parallel.CfgSplit): the graph holds THIS rank's forward only; the exchange of the two noise
+        # predictions and the (two-launch) guidance + update run after every replay
+        self.split = getattr(sampler.model, "cfg_split", None)
+        guided = kw.get("unconditional_conditioning") is not None and kw.get("unconditional_guidance_scale", 1.0) != 1.0
+        if self.split is not None and not guided:
+            self.split = None
+
         def step():
+            if self.split is not None:
+                skw = {k: v for k, v in kw.items() if k not in ("unconditional_conditioning", "unconditional_guidance_scale", "temperature",
+                                                                  "guidance_rescale")}
+                uc = sampler._uncond_with_camera(cond, kw["unconditional_conditioning"], skw)
+                return sampler._own_half(self.split, self.x, cond, self.t, uc, skw), None
             return sampler.p_sample_ddim(self.x, cond, self.t, index=0, noise=self.noise, coef=self.coef, **kw)
+        self._kw = kw
 
         # warm-up on a side stream: packs weights, primes the allocator
         side = torch.cuda.Stream()
@@ -265,6 +279,18 @@ class _GraphedClip:
             self.prologue.replay()
 
     def run(self, x, t_row, coef_row, noise):
+        if self.split is not None:
+            self.x.copy_(x)
+            self.t.copy_(t_row)
+            self.graph.replay()                      # x_prev holds this rank's noise prediction here
+            e_c, e_uc = self.split.exchange(self.x_prev)
+            if self.noise is not None and noise is None:
+                noise = rng.randn(self.x.shape, device=self.x.device)
+            temperature = self._kw.get("temperature", 1.0)
+            if noise is not None and temperature != 1.0:
+                noise = noise * temperature
+            return ops.ddim_cfg_step(self.x, e_c, e_uc, noise, coef_row.contiguous(), self._kw.get("unconditional_guidance_scale", 1.0),
+                                     self._kw.get("guidance_rescale", 0.0))
         if x.data_ptr() != self.x_prev.data_ptr():
             self.x.copy_(x)
         else:
@@ -393,6 +419,52 @@ class DDIMSampler(object):
             img[bi, :, idx] = cond["origin_z_0"][bi, :, idx]
         return img, intermediates
 
+    def _uncond_with_camera(self, c, unconditional_conditioning, kwargs):
+        if kwargs.get("enable_camera_condition") and isinstance(c, dict) and "camera_condition" in c:
+            # shared by reference; the marker key the reference sets on its copy is kept (ddim.py:259-260)
+            uc_cam = dict(c["camera_condition"])
+            uc_cam["is_uc"] = True
+            unconditional_conditioning["camera_condition"] = uc_cam
+        return unconditional_conditioning
+
+    def _own_half(self, split, x, c, t, unconditional_conditioning, kwargs):
+        """This rank's forward of a CFG step under parallel.CfgSplit: rank 0 the conditional, rank 1 the unconditional one."""
+        return self.model.apply_model(x, t, c if split.rank == 0 else unconditional_conditioning, **kwargs).float().contiguous()
+
+    def _predict_noise(self, x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs):
+        """(e_c, e_uc) of one step (ddim.py:252-280); e_uc is None without guidance.  With ``model.cfg_split`` set
+        (parallel.CfgSplit, two ranks) this rank runs ONE of the two forwards and the halves are exchanged."""
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.0:
+            return self.model.apply_model(x, t, c, **kwargs), None
+        if not isinstance(c, (dict, torch.Tensor)):
+            raise NotImplementedError
+        unconditional_conditioning = self._uncond_with_camera(c, unconditional_conditioning, kwargs)
+        camera_cfg = kwargs.get("camera_cfg", 1.0)
+        third = kwargs.get("enable_camera_condition") and camera_cfg != 1.0 and isinstance(c, dict)
+        split = getattr(self.model, "cfg_split", None)
+        if split is not None:
+            if third:
+                raise NotImplementedError("camera_cfg != 1 (a third forward per step) with the CFG split")
+            return split.exchange(self._own_half(split, x, c, t, unconditional_conditioning, kwargs))
+        pair = getattr(self.model, "apply_model_pair", None)
+        if pair is not None:
+            e_c, e_uc = pair(x, t, c, unconditional_conditioning, **kwargs)
+        else:
+            e_c = self.model.apply_model(x, t, c, **kwargs)
+            e_uc = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
+        if third:
+            # third forward without the camera (ddim.py:268-280): model_output += (camera_cfg - 1) w (e_c - e_nc); the term
+            # goes into the unconditional prediction, so the fused guidance + rescale + update kernel runs unchanged
+            scheduler = kwargs.get("camera_cfg_scheduler", "constant")
+            if scheduler not in ("constant", "cosine"):
+                raise NotImplementedError(f"camera_cfg_scheduler {scheduler!r}")
+            c_no_cam = {k: v for k, v in c.items() if k != "camera_condition"}
+            e_nc = self.model.apply_model(x, t, c_no_cam, **kwargs)
+            e_uc = ops.camera_cfg_fold(e_uc.float().contiguous(), e_c.float().contiguous(), e_nc.float().contiguous(),
+                                       (camera_cfg - 1.0) / (1.0 - unconditional_guidance_scale),
+                                       t.contiguous() if scheduler == "cosine" else None)
+        return e_c, e_uc
+
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
                       temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
@@ -406,35 +478,7 @@ class DDIMSampler(object):
         if getattr(self.model, "parameterization", "eps") != "eps":
             raise NotImplementedError("only the eps parameterisation is used by the shipped configs")
         x = x.float().contiguous()
-        e_uc = None
-        if unconditional_conditioning is None or unconditional_guidance_scale == 1.0:
-            e_c = self.model.apply_model(x, t, c, **kwargs)
-        else:
-            if not isinstance(c, (dict, torch.Tensor)):
-                raise NotImplementedError
-            if kwargs.get("enable_camera_condition") and isinstance(c, dict) and "camera_condition" in c:
-                # shared by reference; the marker key the reference sets on its copy is kept (ddim.py:259-260)
-                uc_cam = dict(c["camera_condition"])
-                uc_cam["is_uc"] = True
-                unconditional_conditioning["camera_condition"] = uc_cam
-            pair = getattr(self.model, "apply_model_pair", None)
-            if pair is not None:
-                e_c, e_uc = pair(x, t, c, unconditional_conditioning, **kwargs)
-            else:
-                e_c = self.model.apply_model(x, t, c, **kwargs)
-                e_uc = self.model.apply_model(x, t, unconditional_conditioning, **kwargs)
-            camera_cfg = kwargs.get("camera_cfg", 1.0)
-            if kwargs.get("enable_camera_condition") and camera_cfg != 1.0 and isinstance(c, dict):
-                # third forward without the camera (ddim.py:268-280): model_output += (camera_cfg - 1) w (e_c - e_nc); the term
-                # goes into the unconditional prediction, so the fused guidance + rescale + update kernel runs unchanged
-                scheduler = kwargs.get("camera_cfg_scheduler", "constant")
-                if scheduler not in ("constant", "cosine"):
-                    raise NotImplementedError(f"camera_cfg_scheduler {scheduler!r}")
-                c_no_cam = {k: v for k, v in c.items() if k != "camera_condition"}
-                e_nc = self.model.apply_model(x, t, c_no_cam, **kwargs)
-                e_uc = ops.camera_cfg_fold(e_uc.float().contiguous(), e_c.float().contiguous(), e_nc.float().contiguous(),
-                                           (camera_cfg - 1.0) / (1.0 - unconditional_guidance_scale),
-                                           t.contiguous() if scheduler == "cosine" else None)
+        e_c, e_uc = self._predict_noise(x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs)
         if noise is None and coef is None and float(self.ddim_sigmas[index]) != 0.0:
             shape = (1, *x.shape[1:]) if repeat_noise else x.shape
             noise = rng.randn(shape, device=x.device).expand(x.shape).contiguous()
