@@ -358,7 +358,7 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
                                "has its own conditioning tensors (per-clip prologue inside the timed region); every sampling call "
                                "is ONE clip (UNet batch 2 under CFG) -- clips_in_flight_per_gpu independent calls run on "
                                "their own HIP streams at a time",
-                   "clips_per_gpu": 1, "clips_in_flight_per_gpu": lanes, "parallelism": f"frame-shard{world}" if sharded else f"clip-dp{world}",
+                   "clips_per_gpu": 1, "clips_in_flight_per_gpu": lanes, "parallelism": (sharded if isinstance(sharded, str) else f"frame-shard{world}") if sharded else f"clip-dp{world}",
                    "launch": "hipGraph" if use_graph else "eager"},
         "roofline": roof,
     }
@@ -387,6 +387,9 @@ def main(argv=None, hooks=None):
     """hooks (tests only): dict(device=, backend=, build_model=, synthetic_inputs=, sample_clip=, sync=, extras=False) lets the
     multi-process logic run on CPU with gloo and a stand-in clip."""
     argv = sys.argv[1:] if argv is None else list(argv)
+    if os.environ.get("CCV_BENCH_WATCHDOG"):      # diagnosis: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CCV_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -397,6 +400,8 @@ def main(argv=None, hooks=None):
     ap.add_argument("--lanes", type=int, default=2, help="independent clips in flight per GPU (one host thread + HIP stream + hipGraph set each)")
     ap.add_argument("--frame-shard", action="store_true", help="single-clip latency mode: the N ranks sample EVERY clip together, its 16 frames "
                     "sharded over them (camc2v_amd/parallel.py; eager, strong scaling); default is one independent clip stream per rank")
+    ap.add_argument("--cfg-split", action="store_true", help="single-clip latency mode for 2 ranks: rank 0 runs the conditional, rank 1 the "
+                    "unconditional forward of every step (camc2v_amd/parallel.py: CfgSplit; hipGraph per rank, strong scaling)")
     ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
     args = ap.parse_args(argv)
     hooks = hooks or {}
@@ -443,13 +448,18 @@ def main(argv=None, hooks=None):
     make_inputs = hooks.get("synthetic_inputs", synthetic_inputs)
     run_clip = hooks.get("sample_clip", sample_clip)
     n_sets = 1 if args.same_conditioning else args.steps + args.warmup
-    sharded = bool(args.frame_shard and world > 1)
+    if args.cfg_split and world != 2:
+        raise SystemExit("bench.py: --cfg-split needs exactly 2 ranks")
+    sharded = bool((args.frame_shard or args.cfg_split) and world > 1)     # the ranks sample every clip TOGETHER
     sets = [make_inputs(model, device, rank=0 if sharded else rank, clip=i) for i in range(n_sets)]     # sharded: all ranks work on the same clips
-    use_graph = not args.no_graph and not sharded
+    use_graph = not args.no_graph and not (sharded and args.frame_shard)
     if sharded:
         args.lanes = 1
-        if on_gpu:
+        if on_gpu and args.frame_shard:
             model.model.diffusion_model.enable_frame_sharding()
+        elif on_gpu:
+            from camc2v_amd.parallel import CfgSplit
+            model.cfg_split = CfgSplit()
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if on_gpu else None
     first_ms = {}
@@ -490,7 +500,8 @@ def main(argv=None, hooks=None):
         extras = on_gpu and hooks.get("extras", True) and not args.clips_only
         dom = dominant_kernel(model, device, sets[0]) if extras else None
         skipped = skipped_flops(sets[0]) if extras else None
-        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen, lanes, sharded)
+        line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen, lanes,
+                           ("cfg-split2" if args.cfg_split else sharded) if sharded else False)
         if first_ms:
             line["config"]["first_clip_ms"] = first_ms["v"]    # includes packing, graph capture (a new signature) and caches
         if world == 1 and extras and lanes > 1:      # the same clips one at a time (one stream), for comparison

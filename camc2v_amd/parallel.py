@@ -26,12 +26,23 @@ def current():
     return getattr(_CUR, "ctx", None)
 
 
+def _first_collective(group):
+    """One tiny device collective right away: the backend sets up its device-side resources (communicator, streams, pinned
+    staging buffers) here instead of in the middle of the first sampling step -- with gloo that first call hung when it came
+    right after a hipGraph replay of the same process (seen in the one-GPU rehearsal of `bench.py --cfg-split`)."""
+    if torch.cuda.is_available():
+        t = torch.zeros(8, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, group=group)
+        torch.cuda.current_stream().synchronize()
+
+
 class FrameShard:
     def __init__(self, group=None):
         if not dist.is_initialized():
             raise CcvError("FrameShard needs an initialised torch.distributed process group")
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        _first_collective(group)
 
     def all_reduce_sum(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -58,10 +69,16 @@ class CfgSplit:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world != 2:
             raise CcvError(f"the CFG split is for exactly 2 ranks (conditional / unconditional), the group has {self.world}")
+        _first_collective(group)
 
     def exchange(self, mine):
         """this rank's noise prediction -> (e_cond, e_uncond)"""
         mine = mine.contiguous()
+        # Drain the stream first.  gloo stages device tensors through the host on streams of its own, and ordered behind a hipGraph
+        # replay still in flight on the current stream its copy never started (one-GPU rehearsal of `bench.py --cfg-split`: both
+        # ranks stuck in all_gather; drained first it runs).  RCCL enqueues on the device and should not need it, but that path has not
+        # run anywhere yet; the wait costs the host's run-ahead over one ~17 ms step (the next replay needs the exchanged result anyway).
+        torch.cuda.current_stream().synchronize()
         parts = [torch.empty_like(mine), torch.empty_like(mine)]
         dist.all_gather(parts, mine, group=self.group)
         return parts[0], parts[1]

@@ -253,8 +253,12 @@ class _GraphedClip:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            step()
+            warm = step()
         torch.cuda.current_stream().wait_stream(side)
+        if self.split is not None:
+            # one exchange of the real size before any capture: the backend allocates its staging buffers here (with gloo the first
+            # all_gather of a new size hung when it came right after a graph replay; seen in the one-GPU rehearsal of bench.py)
+            self.split.exchange(warm[0])
         self.prologue = None
         if unet is not None and hasattr(unet, "inputs_only"):
             unet.forget_inputs(self.static.slots)      # the warm-up's derived tensors live outside any graph pool
