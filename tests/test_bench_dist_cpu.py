@@ -141,3 +141,29 @@ def test_bench_refuses_to_run_without_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "no CPU fallback" in (p.stderr + p.stdout)
+
+
+def test_timed_clips_lanes_share_exactly_k_clips_and_reraise_errors():
+    """Device-independent lane logic of bench.timed_clips: any K (odd too) is sampled exactly once each by the lanes, the warm-up runs
+    per lane, and an exception inside a lane thread comes back on the caller's thread."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = []
+
+    def clip(i):
+        seen.append(i)
+        time.sleep(0.01)
+        return torch.tensor([float(i)])
+    for lanes, steps, warmup in ((2, 5, 1), (3, 7, 2), (2, 1, 0)):
+        seen.clear()
+        _, _, out, extra = bench.timed_clips(clip, steps, warmup, after=lambda o: float(o), lanes=lanes)
+        assert seen[:lanes * warmup] == list(range(warmup)) * lanes
+        assert sorted(seen[lanes * warmup:]) == list(range(warmup, warmup + steps))
+        assert float(out) == warmup + steps - 1 and extra == warmup + steps - 1     # `after` sees the LAST clip's output
+
+    def bad(i):
+        if i == 3:
+            raise ValueError("clip 3 failed")
+        return torch.zeros(1)
+    with pytest.raises(ValueError, match="clip 3 failed"):
+        bench.timed_clips(bad, 6, 0, lanes=2)
