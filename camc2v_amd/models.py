@@ -67,12 +67,12 @@ class DynamiCrafter(LatentDiffusionCore):
         return batch[k].to(device=self.device, memory_format=torch.contiguous_format).float()
 
     def get_learned_conditioning(self, c):
-        """Text encoder call (ddpm3d.py:600-611).  The OpenCLIP encoders are third-party code + weights and are not part of
-        this package: assign one to ``self.cond_stage_model`` or hand the embeddings over in the batch (``caption_emb``)."""
+        """Text encoder call (ddpm3d.py:600-611).  ``cond_stage_model`` (camc2v_amd/clip.py: ~354 M parameters whose weights come
+        from the checkpoint) is built by ``build_feeders(encoders=True)``; without it the embeddings come in the batch (``caption_emb``)."""
         enc = getattr(self, "cond_stage_model", None)
         if enc is None:
-            raise CcvError("no text encoder: set model.cond_stage_model (an OpenCLIP text embedder) or pass 'caption_emb' "
-                           "[b, 77, 1024] / 'null_caption_emb' in the batch")
+            raise CcvError("no text encoder attached: call model.build_feeders(encoders=True) (and load the checkpoint) or pass "
+                           "'caption_emb' [b, 77, 1024] / 'null_caption_emb' in the batch")
         return enc.encode(c) if callable(getattr(enc, "encode", None)) else enc(c)
 
     def _text_embeddings(self, batch, n):
@@ -97,7 +97,7 @@ class DynamiCrafter(LatentDiffusionCore):
         if emb is not None:
             return emb(img)
         if batch.get(key) is None:
-            raise CcvError(f"no image encoder: set model.embedder (OpenCLIP ViT-H image embedder) or pass '{key}' in the batch")
+            raise CcvError(f"no image encoder attached: call model.build_feeders(encoders=True) (and load the checkpoint) or pass '{key}' in the batch")
         tok = self.get_input(batch, key)
         if tok.dim() == 4:
             if tok.shape[1] < frames_per_sample:
