@@ -698,6 +698,7 @@ class _InputCache:
     def __init__(self, capacity=24):
         self.capacity = capacity
         self.items = OrderedDict()
+        self.lock = threading.RLock()      # several host threads may run forwards of one module (clips in flight)
 
     @staticmethod
     def key(tag, t):
@@ -707,23 +708,26 @@ class _InputCache:
 
     def get(self, tag, t, make):
         k = self.key(tag, t)
-        hit = self.items.get(k)
-        if hit is not None and hit[0] is t:
-            self.items.move_to_end(k)
-            return hit[1]
-        val = make()
-        self.items[k] = (t, val)  # keeping `t` alive pins id()/data_ptr()
-        while len(self.items) > self.capacity:
-            self.items.popitem(last=False)
-        return val
+        with self.lock:
+            hit = self.items.get(k)
+            if hit is not None and hit[0] is t:
+                self.items.move_to_end(k)
+                return hit[1]
+            val = make()
+            self.items[k] = (t, val)  # keeping `t` alive pins id()/data_ptr()
+            while len(self.items) > self.capacity:
+                self.items.popitem(last=False)
+            return val
 
     def forget(self, tensors):
         ids = {id(t) for t in tensors}
-        for k in [k for k, (t, _) in self.items.items() if id(t) in ids]:
-            del self.items[k]
+        with self.lock:
+            for k in [k for k, (t, _) in self.items.items() if id(t) in ids]:
+                del self.items[k]
 
     def clear(self):
-        self.items.clear()
+        with self.lock:
+            self.items.clear()
 
 
 class UNetModel(nn.Module, _Prepared):
