@@ -661,7 +661,8 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
     __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words
     unsigned char* smw = sm + 4 * 2 * 8192;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA destinations stay in SGPRs
     const int r = lane & 31, hh = lane >> 5;
     const float sl2 = p.scale * 1.4426950408889634f;
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
@@ -760,12 +761,19 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
             }
             const uint16_t* kp = kmain + (long)base * p.k_ls;
             const uint16_t* vp = vmain + (long)base * p.v_ls;
-            const bool full = k0 + 32 <= p.Lk;
+            if (k0 + 32 <= p.Lk) {      // every block but a ragged last one: no per-lane bounds select
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = full || (k0 + 8 * j + lr8) < p.Lk;
-                __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? kp + koff[j] : zero), (lptr_t*)(sK + j * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? vp + voff[j] : zero), (lptr_t*)(sV + j * 1024), 16, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(kp + koff[j]), (lptr_t*)(sK + j * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(vp + voff[j]), (lptr_t*)(sV + j * 1024), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = (k0 + 8 * j + lr8) < p.Lk;
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? kp + koff[j] : zero), (lptr_t*)(sK + j * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? vp + voff[j] : zero), (lptr_t*)(sV + j * 1024), 16, 0, 0);
+                }
             }
         }
         // mask words of the 64 queries (lane l <-> query q0 + l) go to LDS by DMA as well: 4 bytes per lane
@@ -796,23 +804,15 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         const bool on0 = __ballot(mw[0] != 0u) != 0ull;
         const bool on1 = (q0 + 32 < p.Lq) && (__ballot(mw[1] != 0u) != 0ull);
         if (!(on0 || on1)) return;
+        // both 32-query halves always (the matrix pipe has slack, vector issue does not: computing only the half that sees a key cost
+        // eight accumulator moves per k-step and a branch per MFMA in the one-sided blocks, a third of all visited blocks)
         f32x16 sa0 = zero16, sa1 = zero16;
-        if (on0 && on1) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int c = 2 * s + hh;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-                sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
-                sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int c = 2 * s + hh;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-                if (on0) sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
-                else     sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
-            }
+        for (int s = 0; s < 4; ++s) {
+            const int c = 2 * s + hh;
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
+            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
         }
         bf16x8 pf0[2], pf1[2];
         auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
