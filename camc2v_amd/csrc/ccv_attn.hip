@@ -658,9 +658,16 @@ __global__ void sparse_ctr_reset(int slot) {
 }
 
 __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, int slot, int use_xcd_queues) {
-    __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words
+    __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512 + 256];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words + seed table
+    // mask nibble -> four fp32 accumulator seeds (0 for a visible key, -inf for a masked one): the score MFMA chain starts from
+    // them instead of from zero, so S^T comes out of the matrix pipe already masked (S + -inf = -inf) and the 2 vector
+    // instructions per score element of a select are replaced by 2 per FOUR elements (table address) + one ds_read_b128
+    // (carved out of `sm`: with a second __shared__ object hipcc's waitcnt pass drains vmcnt(0) before every LDS read of the loop)
+    float* seed_lut = reinterpret_cast<float*>(sm + 4 * 2 * 8192 + 4 * 512);
     unsigned char* smw = sm + 4 * 2 * 8192;
     const int tid = threadIdx.x;
+    if (tid < 64) seed_lut[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 0.f : NEG_INF;
+    __syncthreads();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA destinations stay in SGPRs
     const int r = lane & 31, hh = lane >> 5;
@@ -790,7 +797,6 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int blk, int stage) {
         const unsigned char* sK = ring + stage * 8192;
@@ -806,23 +812,60 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         if (!(on0 || on1)) return;
         // both 32-query halves always (the matrix pipe has slack, vector issue does not: computing only the half that sees a key cost
         // eight accumulator moves per k-step and a branch per MFMA in the one-sided blocks, a third of all visited blocks)
-        f32x16 sa0 = zero16, sa1 = zero16;
+        f32x16 sa0, sa1;
+        {   // accumulator seeds: register i of a lane is key (i & 3) + 8 (i >> 2) + 4 hh, i.e. nibble 2 (i >> 2) + hh of the mask word
+            const uint32_t lut = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(seed_lut);
+            const uint32_t w0 = mw[0] >> (4 * hh), w1 = mw[1] >> (4 * hh);
+            uint32_t ad[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int c = 2 * s + hh;
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
-            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                ad[g4] = lut + (((w0 >> (8 * g4)) & 0xfu) << 4);
+                ad[4 + g4] = lut + (((w1 >> (8 * g4)) & 0xfu) << 4);
+            }
+            // the four K fragments of the lane travel in the same batch: one LDS round trip in front of the eight score MFMAs
+            const uint32_t kb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(sK) + r * 128;
+            uint32_t ka[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ka[s] = kb + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
+            f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+            bf16x8 kf0, kf1, kf2, kf3;
+            asm volatile(   // inline: a C++ LDS read here makes hipcc drain vmcnt(0), i.e. the DMA ring
+                "ds_read_b128 %8, %12\n\t"
+                "ds_read_b128 %0, %16\n\t"
+                "ds_read_b128 %1, %17\n\t"
+                "ds_read_b128 %2, %18\n\t"
+                "ds_read_b128 %3, %19\n\t"
+                "ds_read_b128 %4, %20\n\t"
+                "ds_read_b128 %5, %21\n\t"
+                "ds_read_b128 %6, %22\n\t"
+                "ds_read_b128 %7, %23\n\t"
+                "ds_read_b128 %9, %13\n\t"
+                "ds_read_b128 %10, %14\n\t"
+                "ds_read_b128 %11, %15\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7),
+                  "=&v"(kf0), "=&v"(kf1), "=&v"(kf2), "=&v"(kf3)
+                : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]),
+                  "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                : "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sa0[j] = t0[j]; sa0[4 + j] = t1[j]; sa0[8 + j] = t2[j]; sa0[12 + j] = t3[j];
+                sa1[j] = t4[j]; sa1[4 + j] = t5[j]; sa1[8 + j] = t6[j]; sa1[12 + j] = t7[j];
+            }
+            const bf16x8 kfr[4] = {kf0, kf1, kf2, kf3};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[0][s], sa0, 0, 0, 0);
+                sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[1][s], sa1, 0, 0, 0);
+            }
         }
-        bf16x8 pf0[2], pf1[2];
-        auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
-            const bool all_visible = __builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu)) != 0;
-            softmax_block32(sa, w, all_visible, hh, sl2, m_r, l_r, oa, pfo);
-        };
-        if (on0) softmax_block(sa0, mw[0], m_run[0], l_run[0], oacc[0], pf0);
-        if (on1) softmax_block(sa1, mw[1], m_run[1], l_run[1], oacc[1], pf1);
         bf16x8 vf[2][2];
-        read_vt_block(sV, lane, hh, vf);
+        read_vt_block(sV, lane, hh, vf);   // while the score MFMAs run
+        bf16x8 pf0[2], pf1[2];
+        // the scores arrive masked (seeds above): the softmax runs its all-visible form
+        if (on0) softmax_block32(sa0, 0xffffffffu, true, hh, sl2, m_run[0], l_run[0], oacc[0], pf0);
+        if (on1) softmax_block32(sa1, 0xffffffffu, true, hh, sl2, m_run[1], l_run[1], oacc[1], pf1);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
