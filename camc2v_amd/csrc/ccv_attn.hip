@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         koff[j] = step * p.k_ls + ((pc ^ ((rowin >> 1) & 7)) << 3);
         voff[j] = step * p.v_ls + ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
     }
-    auto issue = [&](int blk, int stage) {   // 8 K/V DMA pieces + 1 mask-word DMA = 9 vector-memory operations
+    auto issue = [&](int blk, int stage) __attribute__((always_inline)) {   // 8 K/V DMA pieces + 1 mask-word DMA = 9 vector-memory operations
         unsigned char* sK = ring + stage * 8192;
         unsigned char* sV = sK + 4096;
         if (blk < 0) {   // register tokens: rows >= nreg read the zero line
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
 
-    auto compute = [&](int blk, int stage) {
+    auto compute = [&](int blk, int stage) __attribute__((always_inline)) {
         const unsigned char* sK = ring + stage * 8192;
         const unsigned char* sV = sK + 4096;
         const int left = blk < 0 ? p.nreg : min(32, p.Lk - 32 * blk);
@@ -815,12 +815,14 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         f32x16 sa0, sa1;
         {   // accumulator seeds: register i of a lane is key (i & 3) + 8 (i >> 2) + 4 hh, i.e. nibble 2 (i >> 2) + hh of the mask word
             const uint32_t lut = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(seed_lut);
-            const uint32_t w0 = mw[0] >> (4 * hh), w1 = mw[1] >> (4 * hh);
             uint32_t ad[8];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                ad[g4] = lut + (((w0 >> (8 * g4)) & 0xfu) << 4);
-                ad[4 + g4] = lut + (((w1 >> (8 * g4)) & 0xfu) << 4);
+            for (int g4 = 0; g4 < 4; ++g4) {   // two instructions per address, kept opaque: hipcc's own form of the expression takes three
+                uint32_t n0, n1;
+                asm("v_bfe_u32 %0, %1, %2, 4" : "=v"(n0) : "v"(mw[0]), "v"(8 * g4 + 4 * hh));
+                asm("v_bfe_u32 %0, %1, %2, 4" : "=v"(n1) : "v"(mw[1]), "v"(8 * g4 + 4 * hh));
+                asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(ad[g4]) : "v"(n0), "v"(lut));
+                asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(ad[4 + g4]) : "v"(n1), "v"(lut));
             }
             // the four K fragments of the lane travel in the same batch: one LDS round trip in front of the eight score MFMAs
             const uint32_t kb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(sK) + r * 128;
@@ -885,9 +887,9 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
     asm volatile("" ::"v"(my_word));
 
     // ---- two-deep software pipeline: the DMA of the next needed block flies while the current one is multiplied ----
-    int cur = next_block(), stage = 0;
-    if (cur != DONE) issue(cur, 0);
-    while (cur != DONE) {
+    // the loop body exists once per ring stage, so that every LDS address of a stage is lane base + immediate offset
+    int cur = next_block();
+    auto step = [&](int stage) __attribute__((always_inline)) -> bool {
         const int nxt = next_block();
         if (nxt != DONE) {
             issue(nxt, stage ^ 1);
@@ -897,7 +899,14 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         }
         compute(cur, stage);
         cur = nxt;
-        stage ^= 1;
+        return cur != DONE;
+    };
+    if (cur != DONE) {
+        issue(cur, 0);
+        for (;;) {
+            if (!step(0)) break;
+            if (!step(1)) break;
+        }
     }
 
 #pragma unroll
