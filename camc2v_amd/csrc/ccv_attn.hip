@@ -855,26 +855,36 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
                 sa0[j] = t0[j]; sa0[4 + j] = t1[j]; sa0[8 + j] = t2[j]; sa0[12 + j] = t3[j];
                 sa1[j] = t4[j]; sa1[4 + j] = t5[j]; sa1[8 + j] = t6[j]; sa1[12 + j] = t7[j];
             }
+            // one chain after the other (a dependent MFMA issues back to back): the first half's scores are complete while the
+            // second chain still runs, so its softmax starts 4 MFMAs earlier
             const bf16x8 kfr[4] = {kf0, kf1, kf2, kf3};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[0][s], sa0, 0, 0, 0);
-                sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[1][s], sa1, 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[0][s], sa0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[1][s], sa1, 0, 0, 0);
         }
         bf16x8 vf[2][2];
         read_vt_block(sV, lane, hh, vf);   // while the score MFMAs run
-        bf16x8 pf0[2], pf1[2];
-        // the scores arrive masked (seeds above): the softmax runs its all-visible form
-        if (on0) softmax_block32(sa0, 0xffffffffu, true, hh, sl2, m_run[0], l_run[0], oacc[0], pf0);
-        if (on1) softmax_block32(sa1, 0xffffffffu, true, hh, sl2, m_run[1], l_run[1], oacc[1], pf1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the scores arrive masked (seeds above): the softmax runs its all-visible form.  Each half's O^T MFMAs follow its
+        // softmax directly and run under the other half's softmax.
+        if (on0) {
+            bf16x8 pf[2];
+            softmax_block32(sa0, 0xffffffffu, true, hh, sl2, m_run[0], l_run[0], oacc[0], pf);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                if (on0) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf0[s2], oacc[0][d], 0, 0, 0);
-                if (on1) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf1[s2], oacc[1][d], 0, 0, 0);
-            }
+                for (int d = 0; d < 2; ++d) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf[s2], oacc[0][d], 0, 0, 0);
+        }
+        if (on1) {
+            bf16x8 pf[2];
+            softmax_block32(sa1, 0xffffffffu, true, hh, sl2, m_run[1], l_run[1], oacc[1], pf);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf[s2], oacc[1][d], 0, 0, 0);
+        }
     };
 
     // Retire every ordinary vector load (Q fragments, bitmap row) where hipcc can see it: its waitcnt bookkeeping
