@@ -334,7 +334,13 @@ __device__ __forceinline__ void softmax_block32(f32x16& sa, uint32_t w, bool all
     float tmax = NEG_INF;
 #pragma unroll
     for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sa[i]), sa[i + 1]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+    {   // max over the two half-waves: v_permlane32_swap leaves {lo, lo} / {hi, hi} in the two registers -- no LDS round trip
+        // (ds_bpermute) on the critical path of every block
+        const uint32_t tb = __float_as_uint(tmax);
+        const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
+        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(sw[0]), "v"(sw[1]));
+        tmax *= sl2;
+    }
     const float m_new = fmaxf(m_r, tmax);
     const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
     if (!__all(m_new == m_r)) {  // some row maximum moved: rescale the running sums
