@@ -685,6 +685,10 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
     const bool has_reg = p.kreg != nullptr && p.nreg > 0;
     const int ngroups = (p.Lq + 63) >> 6;
     const int nbh = p.B * p.H;
+    const int k_ls32 = (int)p.k_ls, v_ls32 = (int)p.v_ls;
+    const int ppr_ = p.perm_w >> 3;
+    const bool perm_pow2 = p.perm_w && (p.perm_hw & (p.perm_hw - 1)) == 0 && (ppr_ & (ppr_ - 1)) == 0;
+    const int sh_hw = perm_pow2 ? __builtin_ctz(p.perm_hw) : 0, sh_ppr = perm_pow2 ? __builtin_ctz(ppr_) : 0;
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     xcc = (use_xcd_queues == 2) ? (int)(blockIdx.x & 7) : (xcc & 7);   // 2 (A/B aid): the round-robin dispatch label instead
@@ -767,13 +771,24 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
             const int k0 = 32 * blk;
             int base = k0;
             if (p.perm_w) {   // first stored row of the patch (wave-uniform scalar arithmetic)
-                const int f = k0 / p.perm_hw, rem = k0 - f * p.perm_hw;
-                const int patch = rem >> 5, ppr = p.perm_w >> 3;
-                const int py = patch / ppr, px = patch - py * ppr;
+                int f, patch, py, px;
+                if (perm_pow2) {   // every shipped latent size: two shifts instead of two ~22-instruction scalar divisions per block
+                    f = k0 >> sh_hw;
+                    patch = (k0 & (p.perm_hw - 1)) >> 5;
+                    py = patch >> sh_ppr;
+                    px = patch & ((p.perm_w >> 3) - 1);
+                } else {
+                    f = k0 / p.perm_hw;
+                    patch = (k0 - f * p.perm_hw) >> 5;
+                    const int ppr = p.perm_w >> 3;
+                    py = patch / ppr;
+                    px = patch - py * ppr;
+                }
                 base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
             }
-            const uint16_t* kp = kmain + (long)base * p.k_ls;
-            const uint16_t* vp = vmain + (long)base * p.v_ls;
+            // row strides fit 32 bits (checked on the host): one 32x32->64 multiply instead of a 64x64 one
+            const uint16_t* kp = kmain + (long)base * (long)k_ls32;
+            const uint16_t* vp = vmain + (long)base * (long)v_ls32;
             if (k0 + 32 <= p.Lk) {      // every block but a ragged last one: no per-lane bounds select
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1105,6 +1120,8 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
         if (p.mask_bits && p.wave_bits && (p.variant == 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024)) {
             // persistent: 2 workgroups per CU (LDS-bound), fewer when there are fewer 64-query groups than waves
             static std::atomic<int> next_slot{0};
+            CCV_REQUIRE(p.k_ls >= 0 && p.v_ls >= 0 && (long)p.Lk * p.k_ls < (1l << 31) && (long)p.Lk * p.v_ls < (1l << 31), CCV_ESHAPE,
+                        "ccv_attn_fwd: sparse kernel addresses one K/V slice with 32-bit element offsets");
             static const int n_cu = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
