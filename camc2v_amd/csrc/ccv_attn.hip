@@ -754,6 +754,13 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
         koff[j] = step * p.k_ls + ((pc ^ ((rowin >> 1) & 7)) << 3);
         voff[j] = step * p.v_ls + ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
     }
+    long koff_m[4], voff_m[4];   // the same, minus the instruction offset of piece j (in elements)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        koff_m[j] = koff[j] - (j * 1024 - 4096) / 2;
+        voff_m[j] = voff[j] - (j * 1024) / 2;
+        asm volatile("" : "+v"(koff_m[j]), "+v"(voff_m[j]));   // opaque: hipcc otherwise re-derives them per block with 64-bit adds
+    }
     auto issue = [&](int blk, int stage) __attribute__((always_inline)) {   // 8 K/V DMA pieces + 1 mask-word DMA = 9 vector-memory operations
         unsigned char* sK = ring + stage * 8192;
         unsigned char* sV = sK + 4096;
@@ -789,20 +796,22 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, in
             // row strides fit 32 bits (checked on the host): one 32x32->64 multiply instead of a 64x64 one
             const uint16_t* kp = kmain + (long)base * (long)k_ls32;
             const uint16_t* vp = vmain + (long)base * (long)v_ls32;
+            // one M0 value (the middle of the stage) for all eight pieces: the instruction offset moves the LDS destination AND the
+            // global address, so the per-lane source offsets carry the opposite shift (koff_m / voff_m)
+#define CCV_SPARSE_PIECE(j, KSRC, VSRC)                                                                              \
+    __builtin_amdgcn_global_load_lds((gptr_t*)(KSRC), (lptr_t*)sV, 16, (j) * 1024 - 4096, 0);                       \
+    __builtin_amdgcn_global_load_lds((gptr_t*)(VSRC), (lptr_t*)sV, 16, (j) * 1024, 0);
             if (k0 + 32 <= p.Lk) {      // every block but a ragged last one: no per-lane bounds select
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    __builtin_amdgcn_global_load_lds((gptr_t*)(kp + koff[j]), (lptr_t*)(sK + j * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t*)(vp + voff[j]), (lptr_t*)(sV + j * 1024), 16, 0, 0);
-                }
+                CCV_SPARSE_PIECE(0, kp + koff_m[0], vp + voff_m[0]) CCV_SPARSE_PIECE(1, kp + koff_m[1], vp + voff_m[1])
+                CCV_SPARSE_PIECE(2, kp + koff_m[2], vp + voff_m[2]) CCV_SPARSE_PIECE(3, kp + koff_m[3], vp + voff_m[3])
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = (k0 + 8 * j + lr8) < p.Lk;
-                    __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? kp + koff[j] : zero), (lptr_t*)(sK + j * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gptr_t*)(ok ? vp + voff[j] : zero), (lptr_t*)(sV + j * 1024), 16, 0, 0);
-                }
+                const bool ok0 = (k0 + lr8) < p.Lk, ok1 = (k0 + 8 + lr8) < p.Lk, ok2 = (k0 + 16 + lr8) < p.Lk, ok3 = (k0 + 24 + lr8) < p.Lk;
+                CCV_SPARSE_PIECE(0, ok0 ? kp + koff_m[0] : zero + 2048, ok0 ? vp + voff_m[0] : zero)
+                CCV_SPARSE_PIECE(1, ok1 ? kp + koff_m[1] : zero + 1536, ok1 ? vp + voff_m[1] : zero - 512)
+                CCV_SPARSE_PIECE(2, ok2 ? kp + koff_m[2] : zero + 1024, ok2 ? vp + voff_m[2] : zero - 1024)
+                CCV_SPARSE_PIECE(3, ok3 ? kp + koff_m[3] : zero + 512, ok3 ? vp + voff_m[3] : zero - 1536)
             }
+#undef CCV_SPARSE_PIECE
         }
         // mask words of the 64 queries (lane l <-> query q0 + l) go to LDS by DMA as well: 4 bytes per lane
         const int wi = blk < 0 ? 0 : blk;

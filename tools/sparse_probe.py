@@ -61,4 +61,4 @@ for qkv, H, kw, L in calls:
     alg = (2 * L * 3 * H * 64 * 2) / 3 * 4 / 3   # q, k, v read + o written, bf16
     alg = 2 * L * H * 64 * 2 * 4 + kw["mask_bits"].numel() * 4
     print(f"sparse L={L} H={H} b=2: {us:8.1f} us/launch   dense-equivalent {4.0 * L * L * 64 * H * 2 / us / 1e6:7.1f} TF/s   "
-          f"algorithmic bytes {alg / 1e6:.1f} MB (q,k,v,o + mask bits)   CCV_ATTN_XCD={os.environ.get('CCV_ATTN_XCD', '1')}")
+          f"algorithmic bytes {alg / 1e6:.1f} MB (q,k,v,o + mask bits)   CCV_ATTN_XCD={os.environ.get('CCV_ATTN_XCD', '0')}")
