@@ -226,7 +226,9 @@ def gather_latents(dist, world):
 def dominant_kernel(model, device, inputs, reps=20):
     """attn_sparse_kernel (largest share of kernel time in the rocprofv3 trace of this command): the masked epipolar
     attention of the 5 + 5 temporal blocks at 32x32 and 16x16 latents of one CFG step (b = 2: cond + uncond), on the
-    benchmark clip's own masks, timed with HIP events on the launch stream around a hipGraph of those 10 launches.
+    benchmark clip's own masks, timed with HIP events on the launch stream: once in isolation (a hipGraph of those 10
+    launches, warm caches: `us_per_launch_isolated`) and once inside eager CFG steps of the model (`us_per_launch`, the
+    figure the roofline uses and the one the rocprofv3 trace of this command agrees with).
     Algorithmic FLOPs per launch by SURVEY.md section 8(d)'s dense convention (4 Lq Lk 64 H b, mask ignored), and the
     executed share (32-key blocks the kernel visits / all blocks) beside it."""
     from camc2v_amd import ops
@@ -268,11 +270,30 @@ def dominant_kernel(model, device, inputs, reps=20):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * 10)
+    us_isolated = e0.elapsed_time(e1) * 1e3 / (reps * 10)
+    # ... and where the trace sees them: inside the UNet.  Eager CFG steps of the benchmark clip (the forward pair the sampler
+    # runs), HIP events on the launch stream around every sparse-attention launch (ops.SPARSE_PROBE); the first step is warm-up.
+    # This is the figure the roofline uses -- K / V come fresh from the QKV projection and the other layers' traffic has passed
+    # through the caches in between, as in the profiled run.
+    cond, uncond, fs, x_T, _ = inputs
+    t = torch.full((x_T.shape[0],), 439, dtype=torch.long, device=device)
+    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True))
+    ops.SPARSE_PROBE = probe = []
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.SPARSE_PROBE = None
+    per_step = len(probe) // 3
+    timed = probe[per_step:]
+    us = sum(a.elapsed_time(b) for a, b, *_ in timed) * 1e3 / max(1, len(timed)) if timed else us_isolated
     fl = 0.5 * (flops[0] + flops[1])                  # mean over the 10 launches
     fl_exec = 0.5 * (flops[0] * visited[0] + flops[1] * visited[1])
     tf = fl / us / 1e6
-    return dict(kernel="attn_sparse_kernel", us_per_launch=us, flops_per_launch=fl, achieved=tf, frac=tf / PEAK_BF16_TFLOPS,
+    return dict(kernel="attn_sparse_kernel", us_per_launch=us, us_per_launch_isolated=us_isolated, launches_timed_in_model=len(timed),
+                flops_per_launch=fl, achieved=tf, frac=tf / PEAK_BF16_TFLOPS,
                 executed_fraction=fl_exec / fl, effective_tflops=fl_exec / us / 1e6,
                 problem="masked epipolar attention, b=2 (cond+uncond), L=16384 H=5 (x5) and L=4096 H=10 (x5) per CFG step, 4 register "
                         "tokens, benchmark masks; dense FLOP convention 4 Lq Lk 64 H b",
@@ -338,7 +359,8 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
         roof.update(achieved=dom["achieved"], frac=dom["frac"], kernel=dom["kernel"], us_per_launch=dom["us_per_launch"],
                     flops_per_launch=dom["flops_per_launch"], executed_fraction=dom["executed_fraction"],
                     effective_tflops=dom["effective_tflops"], problem=dom["problem"],
-                    visited_block_fraction=dom["visited_block_fraction"])
+                    visited_block_fraction=dom["visited_block_fraction"],
+                    us_per_launch_isolated=dom.get("us_per_launch_isolated"), launches_timed_in_model=dom.get("launches_timed_in_model"))
     if os.path.exists(TRAFFIC_FILE):     # HBM-side bytes per launch of the dominant kernel from this round's PMC passes
         try:
             tr = json.load(open(TRAFFIC_FILE))

@@ -152,6 +152,9 @@ LAST_GEMM_PLAN = None
 # ---------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------
+SPARSE_PROBE = None   # a list: attention() appends (start event, end event, Lq, H, B) per sparse-kernel launch (eager mode only)
+
+
 def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_str=None, scale=None,
               k2=None, v2=None, k2_str=None, v2_str=None, Lk2=0, gate2=1.0,
               mask_bits=None, mask_nb=1, tile_flags=None, wave_bits=None, group_order=None, kreg=None, vreg=None, variant=None,
@@ -208,7 +211,17 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
     if perm is not None:   # (frame tokens, frame width): rows and mask are in 4x8-patch order
         p.perm_hw, p.perm_w = perm
     p.variant = ATTN_VARIANT if variant is None else variant
+    # measurement aid (bench.py): HIP events on the launch stream around the launches ccv_attn_fwd routes to the persistent
+    # sparse kernel (same rule as csrc/ccv_attn.hip: block bitmap given and variant 3 or >= 1024 64-query groups)
+    probe = SPARSE_PROBE if (wave_bits is not None and mask_bits is not None
+                             and (p.variant == 3 or ((Lq + 63) // 64) * H * B >= 1024)) else None
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().ccv_attn_fwd(C.byref(p), _stream()), "ccv_attn_fwd")
+    if probe is not None:
+        e1.record()
+        probe.append((e0, e1, Lq, H, B))
     return out
 
 
