@@ -435,10 +435,12 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
     assert torch.equal(out3, out4)   # each group is still computed by one wave in the same block order
 
 
-def test_attention_patch_order(ops):
+@pytest.mark.parametrize("fh,fw", [(8, 16), (12, 24)])
+def test_attention_patch_order(ops, fh, fw):
     """4x8-patch token order: q/k/v/o rows stay in raster order in memory, the kernel walks them patch by patch and
-    the mask is packed in the same order; the result must equal raster-order masked attention."""
-    B, H, T, fh, fw, nreg = 2, 2, 6, 8, 16, 4
+    the mask is packed in the same order; the result must equal raster-order masked attention.  8x16 frames: the sparse
+    kernel's shift arithmetic (power-of-two patch grid); 12x24: its general division path (288 tokens, 3 patches per row)."""
+    B, H, T, nreg = 2, 2, 6, 4
     hw = fh * fw
     L = T * hw
     C = H * 64
