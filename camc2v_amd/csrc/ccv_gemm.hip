@@ -117,6 +117,89 @@ __device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, c
     *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = geglu_value(p, n, a_, g_);
 }
 
+
+// GroupNorm(32) statistics of the tile just computed (p.gn_partial; bf16 outputs that feed a GroupNorm): sums and sums of squares
+// of every group's channels over this tile's rows, of the values AS STORED (epilogue applied, rounded to bf16), written to slot
+// (row tile inside the instance) * (column tiles) + (column tile) of the instance the tile's rows belong to -- the layout
+// gn_apply's prologue reduces (ccv_norm.hip).  Work per lane: its 4 columns of a row are two channel PAIRS, and a pair never
+// straddles a group (channels per group are even); pair sums accumulate over the wave's row fragments, fold over the 16 row lanes
+// with shuffles, land in LDS (the operand stages are free by now) and 64 threads -- one per (group, moment) -- add up their group's
+// entries in a fixed order: no atomics, bitwise reproducible.  Tile geometry shared by gemm_dma_kernel and gemm_ring_kernel:
+// 2 x 2 waves, wave tile 16 MT x 16 NT, lane = row (lane & 15) x column quad (lane >> 4) of a 16 x 16 fragment.
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row (= the 16 rows of a fragment), no LDS
+    auto step = [](float x, auto ctrl) {
+        constexpr int c = decltype(ctrl)::value;
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), c, 0xf, 0xf, true));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void tile_gn_stats(const CcvGemm& p, const f32x4 (&acc)[MT][NT], int m0, int n0, int tiles_n, unsigned char* smem) {
+    constexpr int BM = 32 * MT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, fr = lane & 15, fg = lane >> 4;
+    // the epilogue of these problems is alpha * acc + bias[n] (+ bias2[batch][n], one batch per tile): fetched once per column quad
+    // (the host admits only problems without activation / residual, whole tiles inside a bias2 batch and an instance)
+    float4 bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.N) {
+            if (p.bias) bv[j] = *reinterpret_cast<const float4*>(p.bias + n);
+            if (p.bias2) {
+                const float4 b2 = *reinterpret_cast<const float4*>(p.bias2 + (long)(m0 / p.rows_per_batch) * p.ldb2 + n);
+                bv[j].x += b2.x; bv[j].y += b2.y; bv[j].z += b2.z; bv[j].w += b2.w;
+            }
+        }
+    }
+    float gs[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) gs[j][0] = gs[j][1] = gs[j][2] = gs[j][3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {     // (every row is inside M -- host check; columns past N multiply the zero line and get no bias: they add 0)
+            const uint32_t lo = pack_bf16x2(acc[i][j][0] * p.alpha + bv[j].x, acc[i][j][1] * p.alpha + bv[j].y);
+            const uint32_t hi = pack_bf16x2(acc[i][j][2] * p.alpha + bv[j].z, acc[i][j][3] * p.alpha + bv[j].w);
+            const float v0 = bf16_to_f32((uint16_t)(lo & 0xffffu)), v1 = bf16_to_f32((uint16_t)(lo >> 16));
+            const float v2 = bf16_to_f32((uint16_t)(hi & 0xffffu)), v3 = bf16_to_f32((uint16_t)(hi >> 16));
+            gs[j][0] += v0 + v1; gs[j][1] += v0 * v0 + v1 * v1;
+            gs[j][2] += v2 + v3; gs[j][3] += v2 * v2 + v3 * v3;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gs[j][k] = row16_sum(gs[j][k]);
+    __syncthreads();   // every wave has read its last operand stage
+    float* ent = reinterpret_cast<float*>(smem);   // [wave][NT][column quad] x (pair 0 sum, sq, pair 1 sum, sq): 4 * NT * 4 * 16 B <= 2.5 KiB
+    if (fr == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(ent + ((wave * NT + j) * 4 + fg) * 4) = make_float4(gs[j][0], gs[j][1], gs[j][2], gs[j][3]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int g = tid >> 1, k = tid & 1, cpg = p.N >> 5;
+        float a = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; c += 2) {      // the pairs of group g, in channel order
+            const int local = c - n0;
+            if (local < 0 || local >= 32 * NT) continue;
+            const int w = local / (16 * NT), rem = local - w * (16 * NT);     // wave column, column inside the wave tile
+            const int j = rem >> 4, f = (rem >> 2) & 3, pr = (rem >> 1) & 1;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)                               // the two wave rows
+                a += ent[(((2 * half + w) * NT + j) * 4 + f) * 4 + 2 * pr + k];
+        }
+        const int inst = m0 / p.gn_rows, row_tile = (m0 - inst * p.gn_rows) / BM;
+        p.gn_partial[((long)inst * p.gn_slots + row_tile * tiles_n + (n0 / (32 * NT))) * 64 + tid] = a;
+    }
+}
+
 // BKT = K-slab depth (bf16 elements): 64 -> 128-byte LDS rows, 2 MFMA k-steps per slab, 64 KiB of LDS for a
 // 128x128 tile (2 workgroups per CU); 32 -> 64-byte rows, 1 k-step per slab, 32 KiB (4-5 workgroups per CU:
 // more waves in flight to hide the global-load latency of short-K problems).
@@ -576,6 +659,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
             }
         });
     });
+    if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -813,6 +897,7 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             }
         });
     });
+    if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
 }
 
 // split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
@@ -1399,6 +1484,34 @@ extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
     return CCV_OK;
 }
 
+// Tile the kernel ccv_gemm would run this problem on, when that kernel can emit GroupNorm statistics (gemm_dma_kernel /
+// gemm_ring_kernel, bf16 in and out, one pass over K)
+static bool gn_tile_dims(const CcvGemm& p, int& bm, int& bn) {
+    if (!plan_ok(p) || astat_fits(p) || p.a_f32 || p.out_f32 || p.geglu || p.act != 0 || p.residual != nullptr) return false;
+    const Plan pl = make_plan(p, true);
+    if (pl.split > 1) return false;
+    if (pl.ring >= 0) { bm = kRing[pl.ring].bm; bn = kRing[pl.ring].bn; return true; }
+    if (pl.ring == FAM_128x160) { bm = 128; bn = 160; return true; }
+    if (pl.ring == FAM_64x160) { bm = 64; bn = 160; return true; }
+    if (!dma_enabled()) return false;
+    int mt, nt;
+    choose_tile(p, mt, nt);
+    bm = 32 * mt;
+    bn = 32 * nt;
+    return true;
+}
+
+extern "C" int32_t ccv_gemm_gn_slots(const CcvGemm* pp, int32_t rows_per_instance) {
+    if (pp == nullptr || rows_per_instance <= 0) return 0;
+    int bm = 0, bn = 0;
+    if (!gn_tile_dims(*pp, bm, bn)) return 0;
+    const CcvGemm& p = *pp;
+    if (p.N % 64 != 0 || p.ldc != p.N || p.M % rows_per_instance != 0 || rows_per_instance % bm != 0) return 0;
+    if (p.bias2 && (p.rows_per_batch <= 0 || p.rows_per_batch % bm != 0)) return 0;     // one bias2 row per tile
+    const long slots = (long)(rows_per_instance / bm) * ((p.N + bn - 1) / bn);
+    return slots <= 512 ? (int32_t)slots : 0;   // ccv_norm.hip: GN_MAX_PARTS
+}
+
 extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_gemm: null params");
     static const bool wide_init = [] {
@@ -1430,6 +1543,8 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(p.lda >= p.K, CCV_ESHAPE, "ccv_gemm: lda=%d < K=%d", p.lda, p.K);
     CCV_REQUIRE(!p.bias2 || (p.rows_per_batch > 0 && p.ldb2 >= p.N && p.ldb2 % 4 == 0), CCV_EINVAL,
                 "ccv_gemm: bias2 needs rows_per_batch > 0 and ldb2 >= N (multiple of 4)");
+    CCV_REQUIRE(!p.gn_partial || (p.gn_rows > 0 && p.gn_slots > 0 && p.split_k <= 1 && p.gn_slots == ccv_gemm_gn_slots(&p, p.gn_rows)), CCV_EINVAL,
+                "ccv_gemm: gn_partial needs gn_rows and gn_slots = ccv_gemm_gn_slots() > 0 for this problem (got rows %d, slots %d)", p.gn_rows, p.gn_slots);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (plan_ok(p) && astat_fits(p)) return dispatch_astat(p, st);
     switch (p.gather) {

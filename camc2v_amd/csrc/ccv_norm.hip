@@ -15,6 +15,7 @@ namespace {
 
 constexpr int GN_GROUPS = 32;
 constexpr int GN_MAX_CHUNKS = 128;
+constexpr int GN_MAX_PARTS = 512;     // slots per instance ccv_groupnorm_apply_parts accepts (statistics from GEMM epilogues)
 constexpr int GN_UNROLL = 8;       // rows a thread has in flight per batch (memory-level parallelism)
 
 // threads per block: a multiple of C/4 (each thread owns 4 fixed channels), <= 1024, >= 256
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(1024) void gn_stats(const void* x, float* partial, 
 template <bool X_F32>
 __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, const float* gamma, const float* beta,
                                                  const float* partial, int rows_per_instance, int C, int silu,
-                                                 float inv_count, float eps) {
+                                                 float inv_count, float eps, int npart) {   // npart: partial slots per instance (<= 128)
     __shared__ float s_sum[GN_GROUPS * 2];
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int cols = C >> 2;
@@ -115,16 +116,18 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
     const float4 bt = reinterpret_cast<const float4*>(beta)[col];
     if (threadIdx.x < 256) {
         const int gk = threadIdx.x >> 2, j = threadIdx.x & 3;   // gk = 2*group + moment
-        const float* pp = partial + (long)inst * nchunk * GN_GROUPS * 2 + gk;
-        float pv[GN_MAX_CHUNKS / 4];
-#pragma unroll
-        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) {
-            const int c = j + 4 * i;
-            pv[i] = (c < nchunk) ? pp[(long)c * GN_GROUPS * 2] : 0.f;
-        }
+        const float* pp = partial + (long)inst * npart * GN_GROUPS * 2 + gk;
         float a = 0.f;
+        for (int base = 0; base < npart; base += GN_MAX_CHUNKS) {   // one round for the chunked statistics pass (<= 128 slots), up to four
+            float pv[GN_MAX_CHUNKS / 4];                            // for statistics from GEMM epilogues (clip-wide norms: <= 512 tiles)
 #pragma unroll
-        for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) a += pv[i];
+            for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) {
+                const int c = base + j + 4 * i;
+                pv[i] = (c < npart) ? pp[(long)c * GN_GROUPS * 2] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < GN_MAX_CHUNKS / 4; ++i) a += pv[i];
+        }
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
         if (j == 0) s_sum[gk] = a;
@@ -411,9 +414,9 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     CCV_LAUNCH_CHECK("ccv_groupnorm(stats)");
     const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
     if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
+        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
     else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
+        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
     CCV_LAUNCH_CHECK("ccv_groupnorm(apply)");
     return CCV_OK;
 }
@@ -448,10 +451,31 @@ extern "C" int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, co
     dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
     const float* partial = static_cast<const float*>(ws);
     if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
+        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
     else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps);
+        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
     CCV_LAUNCH_CHECK("ccv_groupnorm_apply");
+    return CCV_OK;
+}
+
+// The normalise half on statistics some other kernel produced (the producing GEMM's epilogue, ccv_gemm with gn_partial): `parts`
+// slots of 64 floats per instance, [instances][parts][32 groups][sum, sum of squares], summed here in slot order.
+extern "C" int ccv_groupnorm_apply_parts(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
+                                         int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* partial, int32_t parts,
+                                         void* stream) {
+    CCV_REQUIRE(x && y && gamma && beta && partial, CCV_EINVAL, "ccv_groupnorm_apply_parts: null pointer");
+    CCV_REQUIRE(instances > 0 && instances <= 65535 && rows_per_instance > 0, CCV_EINVAL, "ccv_groupnorm_apply_parts: bad sizes");
+    CCV_REQUIRE(parts > 0 && parts <= GN_MAX_PARTS, CCV_ESHAPE, "ccv_groupnorm_apply_parts: parts=%d must be in 1..%d", parts, GN_MAX_PARTS);
+    CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm_apply_parts: C=%d must be a multiple of 64 and <= 4096", C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
+    const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
+    const float* pr = static_cast<const float*>(partial);
+    if (x_f32)
+        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, pr, rows_per_instance, C, silu, inv_count, eps, (int)parts);
+    else
+        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, pr, rows_per_instance, C, silu, inv_count, eps, (int)parts);
+    CCV_LAUNCH_CHECK("ccv_groupnorm_apply_parts");
     return CCV_OK;
 }
 

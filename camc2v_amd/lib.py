@@ -23,6 +23,7 @@ class CcvGemm(C.Structure):
         ("rows_per_batch", i32), ("act", i32), ("geglu", i32), ("out_f32", i32),
         ("alpha", f32),
         ("ws", vp), ("ws_bytes", i64), ("split_k", i32),
+        ("gn_partial", vp), ("gn_rows", i32), ("gn_slots", i32),
     ]
 
 
@@ -58,6 +59,8 @@ SIGNATURES = {
     "ccv_gemm": (i32, [C.POINTER(CcvGemm), vp]),
     "ccv_gemm_ws_bytes": (i64, [C.POINTER(CcvGemm)]),
     "ccv_gemm_plan": (i32, [C.POINTER(CcvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ccv_gemm_gn_slots": (i32, [C.POINTER(CcvGemm), i32]),
+    "ccv_groupnorm_apply_parts": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
     "ccv_groupnorm_chunks": (i32, [i32, i32, i32]),

@@ -52,8 +52,11 @@ def set_streams_in_flight(n):
 
 def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
          residual=None, act=ACT_NONE, geglu=False, out_f32=False, out=None, gather=GATHER_LINEAR,
-         conv=None, tconv=None, seg_rows=None, alpha=1.0, debug_ws=None):
+         conv=None, tconv=None, seg_rows=None, alpha=1.0, debug_ws=None, gn_rows=None):
     """out[m, n] = epilogue(sum_tap gather(a) @ w_tap^T).  See include/ccv.h (ccv_gemm).
+    gn_rows: the output feeds a GroupNorm(32) whose instances are `gn_rows` consecutive rows; the call then returns
+    (out, stats) with stats = GroupNorm statistics produced by the epilogue (hand them to ``groupnorm(..., stats=)``) or None when
+    the kernel this problem runs on cannot produce them (``groupnorm`` then computes its own).
 
     a: [rows, lda] bf16 or fp32 (2-D, last dim contiguous); w: [N, taps*K] bf16.
     conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw);
@@ -129,6 +132,13 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
             raise CcvError(f"gemm: bias2 must hold {nb2} fp32 rows of >= {N} columns, ldb2 = {ldb2} apart")
     p.rows_per_batch = rows_per_batch
     p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), int(out_f32), alpha
+    stats = None
+    if gn_rows:
+        slots = lib().ccv_gemm_gn_slots(C.byref(p), gn_rows)
+        if slots > 0:
+            part = torch.empty((M // gn_rows, slots, 64), dtype=F32, device=a.device)
+            p.gn_partial, p.gn_rows, p.gn_slots = _ptr(part), gn_rows, slots
+            stats = (part, gn_rows)
     ws_bytes = lib().ccv_gemm_ws_bytes(C.byref(p))
     if ws_bytes > 0:  # split-K workspace for long-K / few-tile problems
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
@@ -141,7 +151,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         check(lib().ccv_gemm_plan(C.byref(p), C.byref(tile), C.byref(split)), "ccv_gemm_plan")
         LAST_GEMM_PLAN = (tile.value, split.value)
     check(lib().ccv_gemm(C.byref(p), _stream()), "ccv_gemm")
-    return out
+    return (out, stats) if gn_rows else out
 
 
 # tests / tuning tools: when TRACK_GEMM_PLAN is set, LAST_GEMM_PLAN = (ring tile index or -1, split-K) of the last call
@@ -264,13 +274,21 @@ def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wa
 # ---------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------
-def groupnorm(x, gamma, beta, *, instances, eps, silu):
-    """x [rows, C] fp32|bf16 -> bf16; statistics per (instance, group of C/32 channels)."""
+def groupnorm(x, gamma, beta, *, instances, eps, silu, stats=None):
+    """x [rows, C] fp32|bf16 -> bf16; statistics per (instance, group of C/32 channels).  stats: what ``gemm(..., gn_rows=)``
+    returned for the GEMM that produced x (the statistics pass is skipped), or None."""
     _dev(x, gamma, beta)
     rows, Cc = _rows(x)
     if rows % instances:
         raise CcvError("groupnorm: rows not divisible by instances")
     y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    if stats is not None:
+        part, gn_rows = stats
+        if gn_rows * instances != rows or part.shape[0] != instances or part.shape[2] != 64 or part.dtype != F32 or not part.is_contiguous():
+            raise CcvError(f"groupnorm: stats were produced for instances of {gn_rows} rows, x has {rows} rows in {instances} instances")
+        check(lib().ccv_groupnorm_apply_parts(_ptr(x), int(x.dtype == F32), _ptr(y), _ptr(gamma), _ptr(beta), instances, gn_rows, Cc, eps,
+                                              int(silu), _ptr(part), part.shape[1], _stream()), "ccv_groupnorm_apply_parts")
+        return y
     ws = torch.empty(lib().ccv_groupnorm_ws_bytes(instances, Cc), dtype=torch.uint8, device=x.device)
     check(lib().ccv_groupnorm(_ptr(x), int(x.dtype == F32), _ptr(y), _ptr(gamma), _ptr(beta), instances,
                               rows // instances, Cc, eps, int(silu), _ptr(ws), _stream()), "ccv_groupnorm")

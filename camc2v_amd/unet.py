@@ -20,6 +20,7 @@ There is no CPU fallback: calling a forward with CPU tensors raises (the CPU res
 in ``oracle/`` and is test infrastructure only).
 """
 import math
+import os
 import threading
 from collections import OrderedDict, namedtuple
 
@@ -49,6 +50,17 @@ def _dev_f32(p):
 
 
 _PACK_LOCK = threading.RLock()
+
+
+# GroupNorm statistics from the producing convolution's epilogue (ops.gemm(gn_rows=) -> ops.groupnorm(stats=)): the second norm of a
+# ResBlock (one instance per frame) and the norms inside a temporal convolution block (one instance per clip: 256-320 tiles, i.e.
+# statistics slots, per instance at 32x32 / 16x16 latents).  Built, parity-tested and measured on MI355X (tools/gn_epilogue_probe.py,
+# profiles/r02_gn_epilogue.txt): every conv + norm pair gets 2-10 us shorter in isolation, 6 / 36 launches per step disappear, but with
+# two clips in flight the frame rate does not move (28.14 off, 27.98 frame-wise only, 28.04 both; one clip at a time +0.2 %) -- most
+# ResBlock convolutions of the 16x16 .. 4x4 levels run split-K, whose reduce kernel owns the epilogue.  Off unless CCV_GN_EPILOGUE=1
+# (frame-wise) / CCV_GN_EPILOGUE_CLIP=1 (clip-wide).
+FRAME_NORM_STATS_FROM_EPILOGUE = os.environ.get("CCV_GN_EPILOGUE", "0") == "1"
+CLIP_NORM_STATS_FROM_EPILOGUE = os.environ.get("CCV_GN_EPILOGUE_CLIP", "0") == "1"
 
 
 def _clip_groupnorm(x, gamma, beta, g, eps, silu):
@@ -604,8 +616,12 @@ class TemporalConvBlock(nn.Module, _Prepared):
         C = self.in_channels
         h = x
         fc = parallel.current()
+        st = None      # GroupNorm statistics of h from the epilogue of the convolution that produced it (whole clip = one instance)
         for i in range(4):
-            z = _clip_groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], g, 1e-5, True)
+            if fc is None:
+                z = ops.groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], instances=g.b, eps=1e-5, silu=True, stats=st)
+            else:
+                z = _clip_groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], g, 1e-5, True)
             last = i == 3
             if fc is not None:     # frames sharded over ranks: the neighbours' edge frames in front of / behind the local ones
                 hw = g.h * g.w
@@ -615,8 +631,14 @@ class TemporalConvBlock(nn.Module, _Prepared):
                 if last:
                     h = h + x
                 continue
-            h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3,
-                         tconv=(g.t, g.h * g.w), residual=x if last else None, out_f32=last)
+            if last:
+                h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w), residual=x,
+                             out_f32=True)
+            elif CLIP_NORM_STATS_FROM_EPILOGUE:
+                h, st = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w),
+                                 gn_rows=g.t * g.h * g.w)
+            else:
+                h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w))
         return h
 
 
@@ -672,9 +694,12 @@ class ResBlock(TimestepBlock, _Prepared):
         off, width = self.emb_slice
         assert width == cout
         h = ops.groupnorm(x, pk["g1"], pk["b1"], instances=g.b * g.t, eps=1e-5, silu=True)
+        # (optionally) the second norm's statistics come out of the first convolution's epilogue where its kernel can produce them
         h = ops.gemm(h, pk["w1"], k=cin, taps=9, bias=pk["cb1"], bias2=emb_all[:, off:], ldb2=emb_all.stride(0),
-                     rows_per_batch=g.t * g.h * g.w, gather=ops.GATHER_CONV3X3, conv=conv)
-        h = ops.groupnorm(h, pk["g2"], pk["b2"], instances=g.b * g.t, eps=1e-5, silu=True)
+                     rows_per_batch=g.t * g.h * g.w, gather=ops.GATHER_CONV3X3, conv=conv,
+                     gn_rows=g.h * g.w if FRAME_NORM_STATS_FROM_EPILOGUE else None)
+        h, st = h if FRAME_NORM_STATS_FROM_EPILOGUE else (h, None)
+        h = ops.groupnorm(h, pk["g2"], pk["b2"], instances=g.b * g.t, eps=1e-5, silu=True, stats=st)
         skip = x
         if "ws" in pk:
             xs = x_bf16 if x_bf16 is not None else x

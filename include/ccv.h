@@ -106,6 +106,13 @@ typedef struct CcvGemm {
     void* ws;               /* optional split-K workspace (ccv_gemm_ws_bytes) or NULL */
     int64_t ws_bytes;
     int32_t split_k;        /* set by the library; callers leave it 0 */
+    /* GroupNorm statistics of the OUTPUT, produced in the epilogue (the GroupNorm(32) that follows a ResBlock / temporal
+     * convolution, openaimodel3d.py:139-147,210-236, lvdm/basics.py normalization): NULL, or [M / gn_rows][gn_slots][32][2] fp32
+     * = per instance (gn_rows consecutive output rows) and output tile the sums and sums of squares of every group's
+     * channels as stored (bf16-rounded), in the layout ccv_groupnorm_apply_parts() reads.  gn_slots must be what
+     * ccv_gemm_gn_slots() returns for this problem (bf16 output, no split-K, tile rows dividing gn_rows). */
+    float* gn_partial;
+    int32_t gn_rows, gn_slots;
 } CcvGemm;
 /* Workspace the library would like for this problem (0 = none).  Long-K, few-tile problems (the 4x4 and 8x8
  * latent layers) are split along K over extra workgroups when the workspace is provided; without it the
@@ -120,6 +127,10 @@ int ccv_gemm(const CcvGemm* p, void* stream);
  * 24576 .. 65536 rows: one workgroup per CU keeps its 128 activation rows in registers, weights stream in 64-column strips);
  * *split = split-K factor. */
 int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
+/* Slots per instance the epilogue statistics of this problem would take (see gn_partial), 0 when the kernel ccv_gemm would run
+ * cannot produce them (fp32 output, GEGLU, split-K, A-stationary / register-staged kernels, tile rows not dividing the
+ * instance, more than 512 slots): the caller then runs ccv_groupnorm as usual. */
+int32_t ccv_gemm_gn_slots(const CcvGemm* p, int32_t rows_per_instance);
 
 /* ------------------------------------------------------------------------------------
  * ccv_attn_fwd: O = softmax(Q K^T * scale [+ mask]) V, head dim 64, bf16 MFMA, fp32 online
@@ -207,6 +218,9 @@ int32_t ccv_groupnorm_chunks(int32_t instances, int32_t rows_per_instance, int32
 int ccv_groupnorm_stats(const void* x, int32_t x_f32, int32_t instances, int32_t rows_per_instance, int32_t C, void* ws, void* stream);
 int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
                         int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* ws, float inv_count, void* stream);
+/* ... and on statistics produced elsewhere (ccv_gemm's gn_partial): `parts` (<= 512) slots of [32][2] fp32 per instance, summed in slot order. */
+int ccv_groupnorm_apply_parts(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
+                              int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* partial, int32_t parts, void* stream);
 
 /* LayerNorm over the last dim, fp32 in -> bf16 out; optional second output
  * y2[r] = y[r] + addend[r % addend_rows] (bf16 [addend_rows, C]) used for the Pluecker-feature add `normed_x + pluker_embedding_features`

@@ -84,6 +84,24 @@ def _plan(built, M, N, K, taps=1, gather=0, geglu=0, a_f32=0):
     return tile.value, split.value
 
 
+def _gn_slots(built, M, N, K, rpi, taps=1, gather=0, out_f32=0, geglu=0):
+    p = built.CcvGemm()
+    p.M, p.N, p.K, p.taps, p.gather, p.geglu, p.out_f32, p.ldc = M, N, K, taps, gather, geglu, out_f32, N
+    return built.lib().ccv_gemm_gn_slots(ctypes.byref(p), rpi)
+
+
+def test_gemm_epilogue_groupnorm_slots_host_logic(built):
+    """Which problems get their GroupNorm statistics from the GEMM epilogue is host code: slots per instance = row tiles inside the
+    instance x column tiles of the kernel the planner picks, 0 where that kernel cannot produce them."""
+    assert _gn_slots(built, 32768, 320, 320, 1024, taps=9, gather=1) == 8 * 2        # ResBlock conv at 32x32 latents: 128x160 tiles, a frame = 8 row tiles
+    assert _gn_slots(built, 32768, 320, 320, 16384, taps=3, gather=2) > 128           # temporal conv, clip-wide norm: every tile of the clip a slot (<= 512)
+    assert _gn_slots(built, 32768, 320, 320, 16384, taps=3, gather=2) <= 512
+    assert _gn_slots(built, 8192, 640, 1280, 256, taps=9, gather=1) == 0              # split-K plan: the reduce kernel owns the epilogue
+    assert _gn_slots(built, 32768, 320, 320, 1024, taps=9, gather=1, out_f32=1) == 0  # fp32 output: not a GroupNorm input of this path
+    assert _gn_slots(built, 32768, 320, 320, 1000, taps=9, gather=1) == 0             # instance rows not whole tiles
+    assert _gn_slots(built, 32768, 960, 320, 1024) == 0                               # A-stationary kernel
+
+
 def test_gemm_planner_host_logic(built):
     """Kernel selection is host code (no device work): the model's layer classes map to the kernels the sweep
     in profiles/ found fastest, and the workspace request always matches the planned split."""

@@ -517,6 +517,50 @@ def test_groupnorm(ops, C, inst, rpi, f32, silu):
     assert_close(y.reshape(inst, rpi, C), ref.permute(0, 2, 1), 1e-2, "groupnorm")
 
 
+@pytest.mark.parametrize("frames,side,cin,cout", [(32, 32, 320, 320), (32, 16, 640, 640), (8, 16, 960, 640), (32, 8, 1280, 1280), (4, 32, 640, 320)])
+def test_groupnorm_statistics_from_the_conv_epilogue(ops, frames, side, cin, cout):
+    """ResBlock order conv3x3 (+bias, +per-frame embedding) -> GroupNorm+SiLU: the convolution's epilogue hands the norm its
+    statistics (gn_rows = pixels per frame); the normalised result must match the norm that makes its own statistics pass over
+    the same bf16 tensor (same values summed, in another order) and the fp32 reference."""
+    from camc2v_amd import pack
+    rows = frames * side * side
+    x = rnd(rows, cin, seed=60)
+    w = pack.pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=torch.Generator().manual_seed(61)) * 0.02).to(dev()))
+    bias = rnd(cout, seed=62, dtype=torch.float32) * 0.1
+    emb = rnd(2, cout, seed=63, dtype=torch.float32) * 0.2
+    gamma = 1.0 + rnd(cout, seed=64, dtype=torch.float32) * 0.1
+    beta = rnd(cout, seed=65, dtype=torch.float32) * 0.1
+    kw = dict(k=cin, taps=9, bias=bias, bias2=emb, ldb2=emb.stride(0), rows_per_batch=rows // 2, gather=ops.GATHER_CONV3X3,
+              conv=(side, side, side, side, 1, 0))
+    ops.TRACK_GEMM_PLAN = True
+    try:
+        h, st = ops.gemm(x, w, gn_rows=side * side, **kw)
+        plan = ops.LAST_GEMM_PLAN
+    finally:
+        ops.TRACK_GEMM_PLAN = False
+    h0 = ops.gemm(x, w, **kw)
+    assert torch.equal(h, h0)
+    y0 = ops.groupnorm(h0, gamma, beta, instances=frames, eps=1e-5, silu=True)
+    if st is None:
+        assert plan[1] > 1, f"no epilogue statistics although the plan {plan} does not split K"
+        return
+    part, gn_rows = st
+    assert gn_rows == side * side and part.shape[0] == frames and part.shape[2] == 64
+    # the slots add up to the plain sums of the stored values
+    hv = h.float().reshape(frames, side * side, 32, cout // 32)
+    want = torch.stack([hv.sum((1, 3)), (hv * hv).sum((1, 3))], -1).reshape(frames, 64)
+    got = part.sum(1)
+    assert_close(got, want, 2e-4, "epilogue statistics")
+    y = ops.groupnorm(h, gamma, beta, instances=frames, eps=1e-5, silu=True, stats=st)
+    d = (y.float() - y0.float()).abs()
+    assert d.max().item() <= 2.0 ** -6 * max(1.0, y0.float().abs().max().item()), d.max().item()   # at most a bf16 rounding step apart
+    assert (d > 0).float().mean().item() < 0.02
+    ref = F.silu(F.group_norm(h.float().reshape(frames, side * side, cout).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1)
+    assert_close(y.reshape(frames, side * side, cout), ref, 1e-2, "groupnorm on epilogue statistics")
+    with pytest.raises(Exception):
+        ops.groupnorm(h, gamma, beta, instances=frames // 2, eps=1e-5, silu=True, stats=st)
+
+
 @pytest.mark.parametrize("C", [64, 320, 512, 640, 1280, 2048])
 def test_layernorm(ops, C):
     rows = 1000
