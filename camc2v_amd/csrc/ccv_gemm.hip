@@ -200,6 +200,11 @@ __device__ __forceinline__ void tile_gn_stats(const CcvGemm& p, const f32x4 (&ac
     }
 }
 
+// Tiles / gathers that have a statistics-emitting kernel instance (the ones the model's unsplit convolutions at 32x32 and 16x16
+// latents run on: 128x160 and 128x128 / 64x128 family tiles, the 4-deep 128x160 ring; 3x3 and temporal convolutions)
+constexpr bool gn_dma_tile(int mt, int nt, int gather) { return (gather == 1 || gather == 2) && ((mt == 4 && nt == 5) || (mt == 4 && nt == 4) || (mt == 2 && nt == 4)); }
+constexpr bool gn_ring_tile(int mt, int nt, int stages, int gather) { return (gather == 1 || gather == 2) && mt == 4 && nt == 5 && stages == 4; }
+
 // BKT = K-slab depth (bf16 elements): 64 -> 128-byte LDS rows, 2 MFMA k-steps per slab, 64 KiB of LDS for a
 // 128x128 tile (2 workgroups per CU); 32 -> 64-byte rows, 1 k-step per slab, 32 KiB (4-5 workgroups per CU:
 // more waves in flight to hide the global-load latency of short-K problems).
@@ -442,8 +447,8 @@ __device__ __attribute__((aligned(16))) unsigned char g_zero_line[16];
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-template <int MT, int NT, int GATHER>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
+template <int MT, int NT, int GATHER, bool GN = false>   // GN: instances that end with tile_gn_stats (their own kernels: the tail costs
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 15-50 VGPRs, which the plain instances must not pay)
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions per wave and slab (8 rows each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -659,7 +664,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {
             }
         });
     });
-    if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+    if constexpr (GN) {
+        if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -691,7 +698,7 @@ struct WaitSlab<PER, 0> {
     static __device__ __forceinline__ void run(int) { wait_vm_barrier<0>(); }
 };
 
-template <int MT, int NT, int ST, int GATHER>
+template <int MT, int NT, int ST, int GATHER, bool GN = false>
 __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void gemm_ring_kernel(const CcvGemm p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 64;           // A pieces (16 rows of 64 B = one DMA wave-instruction) per wave and slab
@@ -897,7 +904,9 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             }
         });
     });
-    if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+    if constexpr (GN) {
+        if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+    }
 }
 
 // split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
@@ -999,6 +1008,19 @@ int launch_dma(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
     const size_t lds = 2 * (BM + BN) * 128;
+    if constexpr (gn_dma_tile(MT, NT, GATHER)) {
+        if (p.gn_partial) {   // the statistics-emitting instance
+            auto kern_gn = gemm_dma_kernel<MT, NT, GATHER, true>;
+            static bool attr_gn = false;
+            if (!attr_gn) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_gn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_gn = true;
+            }
+            hipLaunchKernelGGL(kern_gn, dim3(tiles), dim3(256), lds, st, p);
+            CCV_LAUNCH_CHECK("ccv_gemm(dma, GroupNorm statistics)");
+            return CCV_OK;
+        }
+    }
     auto kern = gemm_dma_kernel<MT, NT, GATHER>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1022,6 +1044,19 @@ int launch_ring(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * (p.split_k > 1 ? p.split_k : 1);
     const size_t lds = (size_t)ST * (BM + BN) * RING_BK * 2;
+    if constexpr (gn_ring_tile(MT, NT, ST, GATHER)) {
+        if (p.gn_partial) {   // the statistics-emitting instance
+            auto kern_gn = gemm_ring_kernel<MT, NT, ST, GATHER, true>;
+            static bool attr_gn = false;
+            if (!attr_gn) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_gn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_gn = true;
+            }
+            hipLaunchKernelGGL(kern_gn, dim3(tiles), dim3(256), lds, st, p);
+            CCV_LAUNCH_CHECK("ccv_gemm(ring, GroupNorm statistics)");
+            return CCV_OK;
+        }
+    }
     auto kern = gemm_ring_kernel<MT, NT, ST, GATHER>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1490,15 +1525,18 @@ static bool gn_tile_dims(const CcvGemm& p, int& bm, int& bn) {
     if (!plan_ok(p) || astat_fits(p) || p.a_f32 || p.out_f32 || p.geglu || p.act != 0 || p.residual != nullptr) return false;
     const Plan pl = make_plan(p, true);
     if (pl.split > 1) return false;
-    if (pl.ring >= 0) { bm = kRing[pl.ring].bm; bn = kRing[pl.ring].bn; return true; }
-    if (pl.ring == FAM_128x160) { bm = 128; bn = 160; return true; }
-    if (pl.ring == FAM_64x160) { bm = 64; bn = 160; return true; }
-    if (!dma_enabled()) return false;
-    int mt, nt;
-    choose_tile(p, mt, nt);
+    if (pl.ring >= 0) {
+        bm = kRing[pl.ring].bm; bn = kRing[pl.ring].bn;
+        return gn_ring_tile(bm / 32, bn / 32, kRing[pl.ring].st, p.gather);
+    }
+    int mt = 0, nt = 0;
+    if (pl.ring == FAM_128x160) { mt = 4; nt = 5; }
+    else if (pl.ring == FAM_64x160) { mt = 2; nt = 5; }
+    else if (!dma_enabled()) return false;
+    else choose_tile(p, mt, nt);
     bm = 32 * mt;
     bn = 32 * nt;
-    return true;
+    return gn_dma_tile(mt, nt, p.gather);
 }
 
 extern "C" int32_t ccv_gemm_gn_slots(const CcvGemm* pp, int32_t rows_per_instance) {
