@@ -107,7 +107,7 @@ typedef struct CcvGemm {
     int64_t ws_bytes;
     int32_t split_k;        /* set by the library; callers leave it 0 */
     /* GroupNorm statistics of the OUTPUT, produced in the epilogue (the GroupNorm(32) that follows a ResBlock / temporal
-     * convolution, openaimodel3d.py:139-147,210-236, lvdm/basics.py normalization): NULL, or [M / gn_rows][gn_slots][32][2] fp32
+     * convolution, openaimodel3d.py:175-182,210-236,255-266, lvdm/basics.py:78-91): NULL, or [M / gn_rows][gn_slots][32][2] fp32
      * = per instance (gn_rows consecutive output rows) and output tile the sums and sums of squares of every group's
      * channels as stored (bf16-rounded), in the layout ccv_groupnorm_apply_parts() reads.  gn_slots must be what
      * ccv_gemm_gn_slots() returns for this problem (bf16 output, no split-K, tile rows dividing gn_rows). */
