@@ -6,6 +6,7 @@ on torch's current stream.  There is no CPU path: a CPU tensor raises.
 """
 import ctypes as C
 import math
+import threading
 
 import torch
 
@@ -162,6 +163,40 @@ LAST_GEMM_PLAN = None
 # ---------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------
+_ctr_tls = threading.local()
+
+
+class queue_counter_arena:
+    """One zero-filled int32 buffer for the work-queue counters of all sparse-attention launches issued by this thread inside the
+    ``with`` block (a UNet forward: one fill launch instead of one per attention call).  Rows are handed out in order and never
+    reused inside the block, so launches may overlap freely; calls beyond ``rows`` (or on another device) allocate their own."""
+
+    def __init__(self, device, rows=32):
+        self.device, self.rows = device, rows
+
+    def __enter__(self):
+        self.prev = getattr(_ctr_tls, "arena", None)
+        _ctr_tls.arena = [torch.zeros(8 * self.rows, dtype=torch.int32, device=self.device), 0, self.rows]
+        return self
+
+    def __exit__(self, *exc):
+        _ctr_tls.arena = self.prev
+        return False
+
+
+def in_queue_counter_arena():
+    return getattr(_ctr_tls, "arena", None) is not None
+
+
+def _queue_counters(device):
+    a = getattr(_ctr_tls, "arena", None)
+    if a is not None and a[1] < a[2] and a[0].device == device:
+        row = a[0][8 * a[1]: 8 * a[1] + 8]
+        a[1] += 1
+        return row
+    return torch.zeros(8, dtype=torch.int32, device=device)
+
+
 SPARSE_PROBE = None   # a list: attention() appends (start event, end event, Lq, H, B) per sparse-kernel launch (eager mode only)
 
 
@@ -206,7 +241,7 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
         if wave_bits is not None:
             # the persistent sparse kernel's work-queue counters: caller-owned and zeroed here, so that launches of several
             # streams / replays of several graphs may overlap (no state kept in the library)
-            ctr = torch.zeros(8, dtype=torch.int32, device=q.device)
+            ctr = _queue_counters(q.device)
             p.queue_counters = _ptr(ctr)
             p.wave_bits = _ptr(wave_bits)
             p.wave_words = wave_bits.shape[-1]
@@ -257,7 +292,7 @@ def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wa
     p.scale = scale if scale is not None else 1.0 / math.sqrt(64.0)
     p.mask_bits, p.mask_words, p.mask_bs, p.mask_nb = _ptr(mask_bits), mask_bits.shape[-1], mask_bits.shape[-2] * mask_bits.shape[-1], mask_nb
     p.wave_bits, p.wave_words, p.wave_bs = _ptr(wave_bits), wave_bits.shape[-1], wave_bits.shape[-2] * wave_bits.shape[-1]
-    ctr = torch.zeros(8, dtype=torch.int32, device=q.device)     # caller-owned work-queue counter (see ``attention``)
+    ctr = _queue_counters(q.device)     # caller-owned work-queue counter (see ``attention``)
     p.queue_counters = _ptr(ctr)
     if group_order is not None:
         p.group_order, p.order_bs = _ptr(group_order), group_order.shape[-1]

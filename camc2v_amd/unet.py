@@ -1058,6 +1058,9 @@ class UNetModel(nn.Module, _Prepared):
                 xl = x[:, :, fc.f0:fc.f0 + fc.t_loc].contiguous()
                 yl = self.forward(xl, timesteps, context, None, fs, camera_condition, cfg_shared_input, **kwargs)
                 return torch.cat(shard.all_gather(yl), 2)
+        if not ops.in_queue_counter_arena():   # one zeroed buffer for the queue counters of this forward's sparse attentions (per thread)
+            with ops.queue_counter_arena(x.device):
+                return self.forward(x, timesteps, context, None, fs, camera_condition, cfg_shared_input, **kwargs)
         pk = self._pk()
         b0, _, t, H, W = x.shape
         shared = bool(cfg_shared_input)
