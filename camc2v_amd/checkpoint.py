@@ -92,7 +92,14 @@ def load_checkpoints(model, model_cfg, report=None):
     log.info(">>> Load weights from pretrained checkpoint")
     try:
         obj = torch.load(ckpt, map_location="cpu", weights_only=True)
-    except Exception:   # Lightning / DeepSpeed files carry pickled hyper-parameter objects next to the tensors
+    except Exception as e:   # Lightning / DeepSpeed files carry pickled hyper-parameter objects next to the tensors
+        # the reference loads with full unpickling (main/utils_train.py:170: torch.load(ckpt, map_location="cpu")), which runs
+        # whatever code the file names: do that only for files the caller trusts, and say so
+        if os.environ.get("CCV_CHECKPOINT_WEIGHTS_ONLY", "0") == "1":
+            raise RuntimeError(f"{ckpt}: not loadable with weights_only=True ({type(e).__name__}: {e}) and CCV_CHECKPOINT_WEIGHTS_ONLY=1 "
+                               "forbids full unpickling") from e
+        log.warning("%s is not a tensors-only file (%s: %s): loading it with full unpickling, as the reference does -- only do this "
+                    "with checkpoints you trust (CCV_CHECKPOINT_WEIGHTS_ONLY=1 refuses instead)", ckpt, type(e).__name__, str(e)[:200])
         obj = torch.load(ckpt, map_location="cpu", weights_only=False)
     container, sd = extract_state_dict(obj)
     rep = load_state_dict_with_report(model, sd, container)

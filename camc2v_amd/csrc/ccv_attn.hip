@@ -664,7 +664,10 @@ __global__ void sparse_ctr_reset(int slot) {
 }
 
 __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, int slot, int use_xcd_queues) {
-    __shared__ __attribute__((aligned(16))) unsigned char sm[4 * 2 * 8192 + 4 * 512 + 256];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words + seed table
+    // aligned(256): the seed-table address is formed as (nibble << 4) | lut (v_lshl_or_b32), which needs the low 8 bits of the table's
+    // LDS address clear (table offset 0x10800 + a 256-byte aligned base)
+    __shared__ __attribute__((aligned(256))) unsigned char sm[4 * 2 * 8192 + 4 * 512 + 256];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words + seed table
+    static_assert((4 * 2 * 8192 + 4 * 512) % 256 == 0, "seed table offset must keep the low 8 address bits clear");
     // mask nibble -> four fp32 accumulator seeds (0 for a visible key, -inf for a masked one): the score MFMA chain starts from
     // them instead of from zero, so S^T comes out of the matrix pipe already masked (S + -inf = -inf) and the 2 vector
     // instructions per score element of a select are replaced by 2 per FOUR elements (table address) + one ds_read_b128

@@ -225,8 +225,15 @@ __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* f
 }
 
 // F [B, T, T, 3, 3] -> packed mask words; query (t1,p1) row, key (t2,p2) column.
-// Arithmetic mirrors model/camcontexti2v.py:229-239 in fp32 without FMA contraction:
-//   l = F x1; l /= ||l_xy||; visible <=> |l . x2| < d*sqrt(2)/2.
+// Arithmetic mirrors model/camcontexti2v.py:229-239 in fp32:  l = F x1; l /= ||l_xy||; visible <=> |l . x2| < d*sqrt(2)/2.
+// The reference evaluates both 3-term dot products as K = 3 matrix products, i.e. as the sequential chain
+// acc = a0 b0 (rounded), acc = fma(a1, b1, acc), acc = fma(a2, 1, acc) = acc + a2: written out below with explicit rounding
+// steps, which reproduces the reference's masks bit for bit (tests/golden/geometry_bits.npz: 0 of 10.4 M bits differ at
+// every resolution; plain mul/add or the reverse chain flips 3-19 bits within an ulp of the threshold).
+__device__ __forceinline__ float dot3_chain(float a0, float b0, float a1, float b1, float a2) {
+    return __fadd_rn(__fmaf_rn(a1, b1, __fmul_rn(a0, b0)), a2);
+}
+
 __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int T, int Tk, int H, int W, float d,
                                      int words, int ktiles, int64_t nwords_total, int perm_w) {
 #pragma clang fp contract(off)
@@ -251,16 +258,16 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
             const int t2 = key / HW, p2 = key % HW;
             if (t2 != t2_cached) {
                 const float* f = F + ((b * T + t1) * Tk + t2) * 9;
-                const float a0 = f[0] * x1 + f[1] * y1 + f[2];
-                const float a1 = f[3] * x1 + f[4] * y1 + f[5];
-                const float a2 = f[6] * x1 + f[7] * y1 + f[8];
-                const float nrm = sqrtf(a0 * a0 + a1 * a1);
-                l0 = a0 / nrm; l1 = a1 / nrm; l2 = a2 / nrm;
+                const float a0 = dot3_chain(f[0], x1, f[1], y1, f[2]);
+                const float a1 = dot3_chain(f[3], x1, f[4], y1, f[5]);
+                const float a2 = dot3_chain(f[6], x1, f[7], y1, f[8]);
+                const float nrm = __fsqrt_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)));
+                l0 = __fdiv_rn(a0, nrm); l1 = __fdiv_rn(a1, nrm); l2 = __fdiv_rn(a2, nrm);
                 t2_cached = t2;
             }
             const float x2 = (float)(p2 % W) * d + d / 2.0f - 0.5f;
             const float y2 = (float)(p2 / W) * d + d / 2.0f - 0.5f;
-            const float dist = fabsf(l0 * x2 + l1 * y2 + l2);
+            const float dist = fabsf(dot3_chain(l0, x2, l1, y2, l2));
             word |= (dist < thr ? 1u : 0u) << j;
         }
         bits[i] = word;

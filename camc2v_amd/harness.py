@@ -2,12 +2,16 @@
 PyTorch-Lightning (reference flow: CamContextI2V/02_generate_videos.py:197-355 -> main/trainer.py:80,146-194 -> ImageLogger
 (main/callbacks.py:163-196, 238-245) -> model.log_images -> utils/save_video.py:65-157).
 
-    python generate.py <eval_config.yaml> [--out DIR] [--num-samples N] [--synthetic-data] [--random-init] [--no-graph] [--lanes L]
+    python generate.py <eval_config.yaml> [--out DIR] [--num-samples N] [--synthetic-data] [--random-init] [--no-graph] [--lanes L] [--seed S]
 
 What is honoured from the yaml: ``model`` (target / params / pretrained_checkpoint), ``data.params.{batch_size, test,
 test_max_n_samples}``, ``lightning.callbacks.batch_logger.params.{log_images_kwargs, test_directory}``.  One process per GPU
 (RANK / WORLD_SIZE from torchrun): the test set is sharded over ranks like Lightning's DistributedSampler does and every rank
 writes its own samples (``log_all_gpus: True`` in the reference's eval config); no collective is needed.
+
+Randomness: every test batch draws (start latent, per-step DDIM noise at eta = 1, first-stage posterior sample) from a generator
+of its own seeded from ``--seed`` (default 20230211 = the reference's, main/trainer.py:21,62) and the dataset index of the
+batch's first sample, so a sample's video does not depend on the lane, the rank, the world size or the run that produced it.
 """
 import argparse
 import logging
@@ -18,6 +22,7 @@ import time
 import torch
 import yaml
 
+from . import rng
 from .checkpoint import load_checkpoints
 from .config import instantiate_from_config
 from .data import SyntheticRealEstate, collate
@@ -73,7 +78,8 @@ def build_dataset(cfg, synthetic=False, num_samples=None):
     return ds, int(dcfg.get("batch_size", 1)), int(n)
 
 
-def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None, lanes=1, encoders=None):
+def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=False, use_graph=True, device=None, lanes=1, encoders=None,
+             seed=20230211):
     """Returns the list of sample directories written by this rank."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if device is None:
@@ -92,7 +98,8 @@ def generate(cfg, out_dir=None, synthetic=False, num_samples=None, random_init=F
 
     def one_batch(s):
         batch = collate([ds[i] for i in idx[s:s + batch_size]])
-        logs = model.log_images(batch, split="test", use_graph=use_graph, **kw)
+        with rng.seeded(int(seed) * 1000003 + idx[s], device):      # this batch's own stream of draws (module docstring)
+            logs = model.log_images(batch, split="test", use_graph=use_graph, **kw)
         logs = prepare_to_log(logs, -1, True)
         return log_evaluation(logs, save_dir, save_fps=7, rescale=True, print_out=(rank == 0))
 
@@ -147,10 +154,12 @@ def main(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--encoders", action="store_true", help="build the OpenCLIP embedders even for the synthetic dataset")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (host thread + HIP stream each)")
+    ap.add_argument("--seed", type=int, default=20230211, help="base seed; every batch draws from a generator seeded with (seed, dataset index)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s: %(message)s")
     with open(args.config) as f:
         cfg = yaml.safe_load(f)
-    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph, lanes=args.lanes, encoders=True if args.encoders else None)
+    written = generate(cfg, args.out, args.synthetic_data, args.num_samples, args.random_init, not args.no_graph, lanes=args.lanes, encoders=True if args.encoders else None,
+                       seed=args.seed)
     print(f"wrote {len(written)} sample directories")
     return 0

@@ -9,12 +9,16 @@ their configs are kept on the object; ``build_feeders()`` instantiates the ones 
 attribute names (``first_stage_model``, ``image_proj_model``, ``pose_encoder``, ``multi_cond_latent_adaptor``) so that
 the matching checkpoint slices load.  The OpenCLIP encoders need third-party code and weights and stay inputs.
 """
+import threading
+
 import torch
 
 from . import camera, rng
 from .config import instantiate_from_config
 from .diffusion import LatentDiffusionCore
 from .lib import CcvError
+
+_NULL_PROMPT_LOCK = threading.Lock()
 
 _FEEDER_KEYS = ("first_stage_config", "cond_stage_config", "img_cond_stage_config", "image_proj_stage_config",
                 "pose_encoder_config", "multi_latent_adaptor", "pose_guided_cond_encoder_config")
@@ -86,7 +90,12 @@ class DynamiCrafter(LatentDiffusionCore):
             null = self.get_input(batch, "null_caption_emb")[:1]
         else:
             if not hasattr(self, "null_prompt"):
-                self.null_prompt = self.get_learned_conditioning([""])
+                with _NULL_PROMPT_LOCK:      # several lanes (host thread + stream each) may get here together: one encodes, and the
+                    if not hasattr(self, "null_prompt"):     # result is published only once its kernels have run
+                        null_prompt = self.get_learned_conditioning([""])
+                        if torch.is_tensor(null_prompt) and null_prompt.is_cuda:
+                            torch.cuda.current_stream(null_prompt.device).synchronize()
+                        self.null_prompt = null_prompt
             null = self.null_prompt
         return cond_emb, null
 

@@ -36,6 +36,21 @@ def _first_collective(group):
         torch.cuda.current_stream().synchronize()
 
 
+def _host_staged(group):
+    """gloo stages device tensors through the host on streams of its own: work still in flight on the current stream (a hipGraph
+    replay) must be drained before such a collective is issued (seen in the one-GPU rehearsal of `bench.py --cfg-split`: both ranks
+    stuck in all_gather; drained first it runs).  RCCL ("nccl") enqueues on the device, in stream order: no drain."""
+    return dist.get_backend(group) != "nccl"
+
+
+def broadcast_from_first(t, group=None):
+    """t of the group's first rank on every rank (in place; returns t)."""
+    if _host_staged(group) and t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return t
+
+
 class FrameShard:
     def __init__(self, group=None):
         if not dist.is_initialized():

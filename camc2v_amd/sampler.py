@@ -73,6 +73,18 @@ def _unet_of(model):
     return getattr(getattr(model, "model", None), "diffusion_model", None)
 
 
+def _shared_draw(model, t):
+    """Under the CFG split / frame sharding every rank runs the guidance + update on what must be identical latents, so a draw
+    (start latent, per-step noise) is rank 0's on every rank: each rank's own generator state may differ (reference-style seeding
+    adds the rank; any extra draw on one rank shifts its stream).  A no-op for ordinary (clip-parallel) sampling."""
+    unet = _unet_of(model)
+    for s in (getattr(model, "cfg_split", None), unet.__dict__.get("frame_shard") if unet is not None else None):
+        if s is not None:
+            from . import parallel
+            return parallel.broadcast_from_first(t, s.group)
+    return t
+
+
 class _StaticTree:
     """Device-resident copy of a conditioning tree (dicts / lists / tuples of tensors and plain values) with stable
     addresses: a hipGraph captured on the copies serves every later clip of the same signature -- ``load`` copies a
@@ -289,7 +301,7 @@ class _GraphedClip:
             self.graph.replay()                      # x_prev holds this rank's noise prediction here
             e_c, e_uc = self.split.exchange(self.x_prev)
             if self.noise is not None and noise is None:
-                noise = rng.randn(self.x.shape, device=self.x.device)
+                noise = _shared_draw(self.sampler.model, rng.randn(self.x.shape, device=self.x.device))
             temperature = self._kw.get("temperature", 1.0)
             if noise is not None and temperature != 1.0:
                 noise = noise * temperature
@@ -377,7 +389,7 @@ class DDIMSampler(object):
                 raise NotImplementedError(f"{flag} belongs to the autoregressive demo path, not to the hot path")
         device = self.model.betas.device
         b = shape[0]
-        img = rng.randn(shape, device=device) if x_T is None else x_T.to(device).float().contiguous()
+        img = _shared_draw(self.model, rng.randn(shape, device=device)) if x_T is None else x_T.to(device).float().contiguous()
         steps = self.ddim_timesteps
         total = steps.shape[0]
         intermediates = {"x_inter": [img], "pred_x0": [img]}
@@ -485,7 +497,7 @@ class DDIMSampler(object):
         e_c, e_uc = self._predict_noise(x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs)
         if noise is None and coef is None and float(self.ddim_sigmas[index]) != 0.0:
             shape = (1, *x.shape[1:]) if repeat_noise else x.shape
-            noise = rng.randn(shape, device=x.device).expand(x.shape).contiguous()
+            noise = _shared_draw(self.model, rng.randn(shape, device=x.device).expand(x.shape).contiguous())
         if noise is not None and temperature != 1.0:
             noise = noise * temperature
         x_prev, pred_x0 = ops.ddim_cfg_step(x, e_c.float().contiguous(), None if e_uc is None else e_uc.float().contiguous(),

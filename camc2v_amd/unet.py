@@ -732,14 +732,24 @@ class _InputCache:
         return (tag, id(t), t.data_ptr(), tuple(t.shape), None if getattr(t, "_ccv_static", False) else t._version)
 
     def get(self, tag, t, make):
+        """The derived value is produced on the calling thread's current stream; a hit from ANOTHER stream (two lanes sharing one
+        conditioning tensor in eager mode) waits for the event recorded behind its producer kernels.  Inside a graph capture no event
+        is recorded or waited for: a capture's entries belong to tensors of its own static tree (one set per stream)."""
         k = self.key(tag, t)
         with self.lock:
             hit = self.items.get(k)
+            capturing = torch.cuda.is_current_stream_capturing()
             if hit is not None and hit[0] is t:
                 self.items.move_to_end(k)
+                if hit[2] is not None and not capturing and hit[3] != torch.cuda.current_stream(t.device).cuda_stream:
+                    torch.cuda.current_stream(t.device).wait_event(hit[2])
                 return hit[1]
             val = make()
-            self.items[k] = (t, val)  # keeping `t` alive pins id()/data_ptr()
+            ev = None
+            if t.is_cuda and not capturing:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(t.device))
+            self.items[k] = (t, val, ev, torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0)  # keeping `t` alive pins id()/data_ptr()
             while len(self.items) > self.capacity:
                 self.items.popitem(last=False)
             return val
@@ -747,7 +757,7 @@ class _InputCache:
     def forget(self, tensors):
         ids = {id(t) for t in tensors}
         with self.lock:
-            for k in [k for k, (t, _) in self.items.items() if id(t) in ids]:
+            for k in [k for k, v in self.items.items() if id(v[0]) in ids]:
                 del self.items[k]
 
     def clear(self):
@@ -901,14 +911,14 @@ class UNetModel(nn.Module, _Prepared):
     def inputs_only(self):
         """Context manager: forwards compute the step-invariant inputs of their arguments (filling the input cache) and
         return zeros.  The sampler captures this as the once-per-clip prologue graph."""
-        unet = self
-
+        tls = self.__dict__.setdefault("_inputs_only_tls", threading.local())     # per host thread: another lane's eager forward
+                                                                                   # must not see this thread's capture mode
         class _Ctx:
             def __enter__(self_):
-                unet.__dict__["_inputs_only"] = True
+                tls.on = True
 
             def __exit__(self_, *exc):
-                unet.__dict__["_inputs_only"] = False
+                tls.on = False
         return _Ctx()
 
     def _apply(self, fn, *args, **kwargs):  # .to()/.cuda() move parameters: packed copies become stale
@@ -1076,7 +1086,7 @@ class UNetModel(nn.Module, _Prepared):
         cam = self._camera_inputs(camera_condition, b, t_all, H, W)
         if fc is not None and cam is not None:
             cam = self._local_camera_inputs(cam, fc, H, W)
-        if self.__dict__.get("_inputs_only"):
+        if getattr(self.__dict__.get("_inputs_only_tls"), "on", False):
             return torch.zeros((b, self.out_channels, t, H, W), dtype=torch.float32, device=x.device)
 
         # -- timestep / frame-stride embedding -> one fused projection for all ResBlocks ------------------

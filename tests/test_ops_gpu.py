@@ -640,9 +640,8 @@ def test_pack_mask_matches_numpy(ops):
 
 
 def test_epipolar_mask_bits_vs_oracle(ops, golden_dir):
-    """Native mask build from F.  Tolerance-budgeted: the GPU evaluates the same fp32 formula with
-    its own rounding of the 3-term dot products; flips are confined to pixels within an ulp of the
-    threshold.  Budget: <= 1e-4 of the set bits."""
+    """Native mask build from F: bit-exact (the kernel evaluates the two 3-term dot products as the reference's matrix
+    products do: product, fma, add -- csrc/ccv_misc.hip dot3_chain), flags included."""
     from oracle import geometry_oracle
     fx = np.load(os.path.join(golden_dir, "geometry.npz"))
     for px, key in ((64, "F64"), (256, "F256")):
@@ -656,9 +655,8 @@ def test_epipolar_mask_bits_vs_oracle(ops, golden_dir):
             refbits, refflags = ops.pack_mask(ref.to(dev()))
             diff = (bits ^ refbits).cpu().numpy().view(np.uint32)
             nflip = int(np.unpackbits(diff.view(np.uint8)).sum())
-            assert nflip <= 1e-4 * float(ref.sum()) + 1, f"px={px} d={d}: {nflip} flipped mask bits"
-            if nflip == 0:
-                assert torch.equal(flags, refflags)
+            assert nflip == 0, f"px={px} d={d}: {nflip} flipped mask bits"
+            assert torch.equal(flags, refflags)
 
 
 def test_sampler_camera_guidance_vs_reference_fixture(ops, golden_dir):

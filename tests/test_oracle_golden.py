@@ -218,6 +218,20 @@ def test_geometry_masks_bit_exact(golden_dir):
         assert np.array_equal(m.sum(-1).to(torch.int32).numpy(), fx[f"mask256_d{d}_popcount_rows"]), d
 
 
+def test_geometry_mask_positions_full_size(golden_dir):
+    """The 256 x 256 px masks, positions and not only row counts (tests/golden/geometry_bits.npz: the reference's packed
+    masks at d = 16 / 32 / 64 and the SHA-256 of the packed mask at every resolution, the 16384^2 one included)."""
+    import hashlib
+    fx = np.load(os.path.join(golden_dir, "geometry.npz"))
+    fb = np.load(os.path.join(golden_dir, "geometry_bits.npz"))
+    F256 = torch.from_numpy(fx["F256"])
+    for d in (8, 16, 32, 64):
+        bits = geometry_oracle.pack_mask_bits(geometry_oracle.epipolar_mask(F256, 256 // d, 256 // d, d))
+        assert hashlib.sha256(bits.tobytes()).digest() == fb[f"mask256_d{d}_sha256"].tobytes(), d
+        if d >= 16:
+            assert np.array_equal(bits, fb[f"mask256_d{d}_bits"]), d
+
+
 def test_vae_decode_oracle_vs_reference_fixture(golden_dir):
     """First-stage decoder restatement (oracle/vae_oracle.py) against the reference's AutoencoderKL.decode run by
     oracle/gen_golden_vae.py: full decode, the activation after the middle block, and the clip-level entry."""
