@@ -663,7 +663,23 @@ __global__ void sparse_ctr_reset(int slot) {
     if (threadIdx.x < 8) g_sparse_ctr[slot][threadIdx.x] = 0u;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const CcvAttn p, int slot, int use_xcd_queues) {
+// Kernel arguments: only what this kernel reads, token strides and slice sizes in 32 bits (checked by the launcher).  The whole
+// CcvAttn is ~100 scalar registers of arguments; held live across the block loop it cost 79 scalar spills (v_readlane reloads
+// inside the loop) and a scratch slot.
+struct SparseArgs {
+    const uint16_t* q; const uint16_t* k; const uint16_t* v; uint16_t* o;
+    const uint16_t* kreg; const uint16_t* vreg;
+    const uint32_t* mask_bits; const uint32_t* wave_bits; const int32_t* group_order; uint32_t* queue_counters;
+    int64_t q_bso, q_bsi, k_bso, k_bsi, v_bso, v_bsi, o_bso, o_bsi;
+    int32_t q_ls, k_ls, v_ls, o_ls;
+    int32_t mask_bs, mask_words, mask_nb, wave_bs, wave_words, order_bs;
+    int32_t B, inner, H, Lq, Lk, nreg, perm_hw, perm_w;
+    float scale;
+    int32_t slot, use_xcd_queues;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p) {
+    const int slot = p.slot, use_xcd_queues = p.use_xcd_queues;
     // aligned(256): the seed-table address is formed as (nibble << 4) | lut (v_lshl_or_b32), which needs the low 8 bits of the table's
     // LDS address clear (table offset 0x10800 + a 256-byte aligned base)
     __shared__ __attribute__((aligned(256))) unsigned char sm[4 * 2 * 8192 + 4 * 512 + 256];  // [wave][stage][K 4 KiB | V 4 KiB] + mask words + seed table
@@ -1150,7 +1166,20 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             static const int xcd_queues = [] { const char* e = getenv("CCV_ATTN_XCD"); return e ? atoi(e) : 0; }();   // 0 (default): one chip-wide queue; 1: per-XCD queues
             // (HW_REG_XCC_ID); 2: per-XCD queues with blockIdx & 7 as the label.  Measured on MI355X (profiles/r02_sparse_xcd_queues.txt):
             // the XCD-local queues are SLOWER (32x32 latents 585 -> 621 us, 16x16 168 -> 208 us per b=2 launch), so they stay off
-            hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, p, slot, xcd_queues);
+            const long mask_bs = p.mask_bs, wave_bs = p.wave_bs, order_bs = p.order_bs;
+            CCV_REQUIRE(p.q_ls >= 0 && p.q_ls < (1l << 31) && p.o_ls >= 0 && p.o_ls < (1l << 31) && mask_bs >= 0 && mask_bs < (1l << 31) &&
+                            wave_bs >= 0 && wave_bs < (1l << 31) && order_bs >= 0 && order_bs < (1l << 31), CCV_ESHAPE,
+                        "ccv_attn_fwd: sparse kernel takes 32-bit token strides and mask slice sizes");
+            SparseArgs a;
+            a.q = p.q; a.k = p.k; a.v = p.v; a.o = p.o; a.kreg = p.kreg; a.vreg = p.vreg;
+            a.mask_bits = p.mask_bits; a.wave_bits = p.wave_bits; a.group_order = p.group_order; a.queue_counters = p.queue_counters;
+            a.q_bso = p.q_bso; a.q_bsi = p.q_bsi; a.k_bso = p.k_bso; a.k_bsi = p.k_bsi; a.v_bso = p.v_bso; a.v_bsi = p.v_bsi; a.o_bso = p.o_bso; a.o_bsi = p.o_bsi;
+            a.q_ls = (int32_t)p.q_ls; a.k_ls = (int32_t)p.k_ls; a.v_ls = (int32_t)p.v_ls; a.o_ls = (int32_t)p.o_ls;
+            a.mask_bs = (int32_t)mask_bs; a.mask_words = p.mask_words; a.mask_nb = p.mask_nb; a.wave_bs = (int32_t)wave_bs; a.wave_words = p.wave_words;
+            a.order_bs = (int32_t)order_bs;
+            a.B = p.B; a.inner = p.inner; a.H = p.H; a.Lq = p.Lq; a.Lk = p.Lk; a.nreg = p.kreg ? p.nreg : 0; a.perm_hw = p.perm_hw; a.perm_w = p.perm_w;
+            a.scale = p.scale; a.slot = slot; a.use_xcd_queues = xcd_queues;
+            hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
         }
         else if (p.mask_bits)
             hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);

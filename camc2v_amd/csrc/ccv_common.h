@@ -44,6 +44,31 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// ---- fp16 helpers (the residual stream's hand-off format; raw uint16 storage) ---------------------------
+__device__ __forceinline__ uint32_t ccv_pack_f16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float2 ccv_unpack_f16x2(uint32_t u) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 v = __builtin_bit_cast(h2, u);
+    return make_float2((float)v[0], (float)v[1]);
+}
+// Element kinds of activation tensors handed to the norm / layout kernels
+enum { CCV_BF16 = 0, CCV_F32 = 1, CCV_F16 = 2 };
+// four consecutive elements (index in units of 4 elements) of a bf16 / fp32 / fp16 tensor as floats
+template <int KIND>
+__device__ __forceinline__ float4 ccv_load4(const void* x, long idx4) {
+    if constexpr (KIND == CCV_F32) return reinterpret_cast<const float4*>(x)[idx4];
+    const uint2 u = reinterpret_cast<const uint2*>(x)[idx4];
+    if constexpr (KIND == CCV_F16) {
+        const float2 a = ccv_unpack_f16x2(u.x), b = ccv_unpack_f16x2(u.y);
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below fp32 rounding of the GELU product
 // and far below the bf16 rounding of the stored result); ~12 VALU + 1 v_exp + 1 v_rcp instead of libm erff.

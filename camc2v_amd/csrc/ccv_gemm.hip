@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "ccv_common.h"
 
@@ -33,6 +34,14 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, B>{});
         static_for<B + S, E, S>(f);
     }
+}
+
+// fp16 <-> fp32 (the residual stream's hand-off format, CcvGemm.out_f32 == 2 / res_f16): v_cvt_f16_f32 / v_cvt_f32_f16, round to nearest even
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) { return ccv_pack_f16x2(lo, hi); }
+__device__ __forceinline__ float2 unpack_f16x2(uint32_t u) { return ccv_unpack_f16x2(u); }
+// two-byte outputs: bf16 (out_f32 == 0) or fp16 (out_f32 == 2)
+__device__ __forceinline__ uint32_t pack_out2(const CcvGemm& p, float lo, float hi) {
+    return p.out_f32 == 2 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
 }
 
 __device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, float o[4]) {
@@ -57,17 +66,23 @@ __device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, fl
         for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
     }
     if (p.residual) {
-        const float4 rv = *reinterpret_cast<const float4*>(p.residual + (long)m * p.ldr + n);
-        o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+        if (p.res_f16) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.residual) + (long)m * p.ldr + n);
+            const float2 a = unpack_f16x2(rv.x), b = unpack_f16x2(rv.y);
+            o[0] += a.x; o[1] += a.y; o[2] += b.x; o[3] += b.y;
+        } else {
+            const float4 rv = *reinterpret_cast<const float4*>(static_cast<const float*>(p.residual) + (long)m * p.ldr + n);
+            o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+        }
     }
 }
 
 __device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4]) {
     epilogue_math(p, m, n, o);
-    if (p.out_f32) {
+    if (p.out_f32 == 1) {
         *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
-        uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        uint2 pk = make_uint2(pack_out2(p, o[0], o[1]), pack_out2(p, o[2], o[3]));
         *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + n) = pk;
     }
 }
@@ -90,14 +105,14 @@ __device__ __forceinline__ void store_pair_bf16(uint16_t* crow, int c, uint2 a, 
 
 __device__ int g_wide_store = 1;   // CCV_GEMM_WIDE_STORE=0 clears it (A/B aid)
 __device__ __forceinline__ bool wide_bf16_ok(const CcvGemm& p) {
-    return !p.out_f32 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && g_wide_store != 0;
+    return p.out_f32 != 1 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && g_wide_store != 0;
 }
 
 __device__ __forceinline__ void epilogue_store_pair(const CcvGemm& p, int m, int n, float o0[4], float o1[4]) {
     epilogue_math(p, m, n, o0);
     epilogue_math(p, m, n + 16, o1);
-    store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, make_uint2(pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])),
-                    make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])));
+    store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, make_uint2(pack_out2(p, o0[0], o0[1]), pack_out2(p, o0[2], o0[3])),
+                    make_uint2(pack_out2(p, o1[0], o1[1]), pack_out2(p, o1[2], o1[3])));
 }
 
 // GEGLU: value columns n..n+3 and gate columns n+16..n+19 of the interleaved weight layout
@@ -205,6 +220,31 @@ __device__ __forceinline__ void tile_gn_stats(const CcvGemm& p, const f32x4 (&ac
 constexpr bool gn_dma_tile(int mt, int nt, int gather) { return (gather == 1 || gather == 2) && ((mt == 4 && nt == 5) || (mt == 4 && nt == 4) || (mt == 2 && nt == 4)); }
 constexpr bool gn_ring_tile(int mt, int nt, int stages, int gather) { return (gather == 1 || gather == 2) && mt == 4 && nt == 5 && stages == 4; }
 
+// Workgroup -> (split, tile).  blockIdx is first remapped so that each XCD (blocks with equal blockIdx % 8 under the observed
+// round-robin dispatch: speed only) owns a contiguous range of work items, then the range is walked
+//   tile_order 0: output tiles row-major (N fastest): an XCD holds a few row bands -> its L2 reads A once and all of W;
+//   tile_order 1: column-major (M fastest): an XCD holds a few column bands -> its L2 reads W once and all of A.
+// The library picks the order by which operand is larger (ccv_gemm: weights of the 8x8 / 4x4-latent layers are 10-60 MB against
+// 1-5 MB of activations; with order 0 every one of the 8 XCDs pulled the whole weight matrix through the fabric).
+__device__ __forceinline__ void block_tile(const CcvGemm& p, int BM, int BN, int tiles_n, int& split, int& m0, int& n0) {
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    split = (p.split_k > 1) ? bid % p.split_k : 0;
+    if (p.split_k > 1) bid /= p.split_k;
+    if (p.tile_order) {
+        const int tiles_m = (p.M + BM - 1) / BM;
+        m0 = (bid % tiles_m) * BM;
+        n0 = (bid / tiles_m) * BN;
+    } else {
+        m0 = (bid / tiles_n) * BM;
+        n0 = (bid % tiles_n) * BN;
+    }
+}
+
 // BKT = K-slab depth (bf16 elements): 64 -> 128-byte LDS rows, 2 MFMA k-steps per slab, 64 KiB of LDS for a
 // 128x128 tile (2 workgroups per CU); 32 -> 64-byte rows, 1 k-step per slab, 32 KiB (4-5 workgroups per CU:
 // more waves in flight to hide the global-load latency of short-K problems).
@@ -237,16 +277,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
 
     // ---- XCD-aware tile assignment (bijective for any grid size) ----------------------
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int split = (p.split_k > 1) ? bid % p.split_k : 0;
-    if (p.split_k > 1) bid /= p.split_k;
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    int split, m0, n0;
+    block_tile(p, BM, BN, tiles_n, split, m0, n0);
 
     // ---- per-thread staging geometry ----------------------------------------------------
     const int chunk = tid % CH;  // 16-byte chunk (8 bf16) within the slab
@@ -447,13 +479,36 @@ __device__ __attribute__((aligned(16))) unsigned char g_zero_line[16];
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-template <int MT, int NT, int GATHER, bool GN = false>   // GN: instances that end with tile_gn_stats (their own kernels: the tail costs
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// slab s must have landed; `younger` slabs (PER DMA instructions each per wave) may stay in flight
+template <int PER, int Y>
+struct WaitSlab {
+    static __device__ __forceinline__ void run(int younger) {
+        if (younger >= Y) wait_vm_barrier<PER * Y>();
+        else WaitSlab<PER, Y - 1>::run(younger);
+    }
+};
+template <int PER>
+struct WaitSlab<PER, 0> {
+    static __device__ __forceinline__ void run(int) { wait_vm_barrier<0>(); }
+};
+
+
+// ST = LDS stages: 2 = the loop above (DMA of slab s+1 behind the MFMAs of slab s, drained before every barrier); 3 = ring with
+// counted waits (two slabs in flight, s_waitcnt vmcnt(N) + raw s_barrier, as gemm_ring_kernel but with whole 128-byte rows): for
+// the layers whose time is the sum of their slabs' DMA latencies -- few tiles (<= 1 workgroup per CU anyway) and 10-80 slabs, the
+// 8x8 / 4x4-latent linear layers and temporal convolutions: a two-stage loop pays one exposed L2 / HBM round trip per slab.
+template <int MT, int NT, int GATHER, bool GN = false, int ST = 2>   // GN: instances that end with tile_gn_stats (their own kernels: the tail costs
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 15-50 VGPRs, which the plain instances must not pay)
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions per wave and slab (8 rows each)
+    static_assert(ST == 2 || ST == 3 || ST == 4, "stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                 // [2][BM][128 B]
-    unsigned char* sB = smem + 2 * BM * 128;  // [2][BN][128 B]
+    unsigned char* sA = smem;                  // [ST][BM][128 B]
+    unsigned char* sB = smem + ST * BM * 128;  // [ST][BN][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -461,16 +516,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int split = (p.split_k > 1) ? bid % p.split_k : 0;
-    if (p.split_k > 1) bid /= p.split_k;
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    int split, m0, n0;
+    block_tile(p, BM, BN, tiles_n, split, m0, n0);
 
     // staging geometry: DMA instruction j of this wave fills tile rows 8*(4j+wave) .. +7
     const int lrow = lane >> 3, lchunk = lane & 7;
@@ -575,12 +622,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
 
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) issue(buf ^ 1);
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + fg;
@@ -601,8 +643,32 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+    };
+    if constexpr (ST == 2) {
+        issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            if (s + 1 < s_end) issue(buf ^ 1);
+            multiply(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // ring: ST-1 slabs in flight.  Top of iteration s: slab s has landed (the younger ones may still fly), every wave is past
+        // its reads of slab s-1 (program order + barrier), whose stage therefore takes slab s+ST-1.
+#pragma unroll
+        for (int k = 0; k < ST - 1; ++k)
+            if (s_begin + k < s_end) issue(k);
+        int stage = 0;
+        for (int s = s_begin; s < s_end; ++s) {
+            WaitSlab<AI + BI, ST - 2>::run(s_end - 1 - s);
+            if (s + ST - 1 < s_end) issue(stage == 0 ? ST - 1 : stage - 1);
+            multiply(stage);
+            stage = (stage + 1 == ST) ? 0 : stage + 1;
+        }
+        __syncthreads();   // (the statistics tail reuses the operand stages)
     }
 
     const bool wide = wide_bf16_ok(p);
@@ -681,23 +747,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
 // -------------------------------------------------------------------------------------------------
 constexpr int RING_BK = 32;
 
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-// slab s must have landed; `younger` slabs (PER DMA instructions each per wave) may stay in flight
-template <int PER, int Y>
-struct WaitSlab {
-    static __device__ __forceinline__ void run(int younger) {
-        if (younger >= Y) wait_vm_barrier<PER * Y>();
-        else WaitSlab<PER, Y - 1>::run(younger);
-    }
-};
-template <int PER>
-struct WaitSlab<PER, 0> {
-    static __device__ __forceinline__ void run(int) { wait_vm_barrier<0>(); }
-};
-
 template <int MT, int NT, int ST, int GATHER, bool GN = false>
 __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void gemm_ring_kernel(const CcvGemm p) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
@@ -715,16 +764,8 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = p.N / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int split = (p.split_k > 1) ? bid % p.split_k : 0;
-    if (p.split_k > 1) bid /= p.split_k;
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    int split, m0, n0;
+    block_tile(p, BM, BN, tiles_n, split, m0, n0);
 
     const int lrow = lane >> 2, lchunk = lane & 3;
     int a_base[AI], a_y[AI], a_x[AI], a_col[AI];
@@ -1003,10 +1044,52 @@ inline int choose_split(const CcvGemm& p) {
     return s < 2 ? 1 : (int)s;
 }
 
+// LDS stages of the family kernel for a problem (gemm_dma_kernel: 2 = two-stage loop, 3 / 4 = ring with counted waits).
+// CCV_GEMM_ST (tuning aid, with CCV_GEMM_TUNE=1 re-read per call): 2 / 3 force a depth, 0 / unset = the rule below.
+inline int family_stages(const CcvGemm& p, int bm, int bn) {
+    const int forced = tune_env("CCV_GEMM_ST");
+    if (forced >= 2 && forced <= 4) return forced;
+    static const int env = [] { const char* e = getenv("CCV_GEMM_ST"); return e ? atoi(e) : 0; }();
+    if (env >= 2 && env <= 4) return env;
+    const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * (p.split_k > 1 ? p.split_k : 1);
+    const int nslab = p.taps * (p.K / BK) / (p.split_k > 1 ? p.split_k : 1);
+    // measured (tools/stage_probe.py, cold operands, profiles/r03_gemm_stages.txt): the ring wins only on the M = 512 layers of the
+    // 4x4 latents (-16 ... -40 %: up to ~2 workgroups per CU, each a chain of exposed DMA round trips); from M = 2048 up the third
+    // stage costs the second workgroup per CU and loses 10-30 %
+    return (p.M <= 1024 && tiles <= 512 && nslab >= 4) ? 3 : 2;
+}
+
+template <int MT, int NT, int GATHER, int ST>
+int launch_dma_ring(const CcvGemm& p, hipStream_t st) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
+    const size_t lds = (size_t)ST * (BM + BN) * 128;
+    auto kern = gemm_dma_kernel<MT, NT, GATHER, false, ST>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm(dma ring)");
+    if (p.split_k > 1) {
+        const long total = (long)p.M * (p.N / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
+    }
+    return CCV_OK;
+}
+
 template <int MT, int NT, int GATHER>
 int launch_dma(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
+    if (!p.gn_partial) {
+        const int stages = family_stages(p, BM, BN);
+        if (stages >= 3) return launch_dma_ring<MT, NT, GATHER, 3>(p, st);     // (4 stages measured equal to 3: not instantiated)
+    }
     const size_t lds = 2 * (BM + BN) * 128;
     if constexpr (gn_dma_tile(MT, NT, GATHER)) {
         if (p.gn_partial) {   // the statistics-emitting instance
@@ -1247,7 +1330,7 @@ __device__ __forceinline__ void wait_vm_only() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-enum { AS_BF16_WIDE = 0, AS_BF16 = 1, AS_F32 = 2, AS_GEGLU = 3 };
+enum { AS_BF16_WIDE = 0, AS_BF16 = 1, AS_F32 = 2, AS_GEGLU = 3, AS_F16 = 4 };   // AS_F16: fp16 output (16-byte pair stores), fp16 residual
 
 template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
@@ -1262,10 +1345,12 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     constexpr int STAGE = NSLAB * BN * 128;            // bytes of one weight strip in LDS
     constexpr int NST = 3;                             // ring depth
     constexpr int PIECES = NSLAB * BN / 8 / NWAVE;     // DMA wave-instructions per wave and strip (8 rows x 128 B each)
-    constexpr int EST = MODE == AS_BF16_WIDE ? MT : MODE == AS_GEGLU ? MT : MT * NT;     // vector stores per strip epilogue
+    constexpr int EST = (MODE == AS_BF16_WIDE || MODE == AS_F16) ? MT : MODE == AS_GEGLU ? MT : MT * NT;     // vector stores per strip epilogue
     constexpr int NL = (HAS_BIAS ? NT : 0) + (HAS_RES ? MT * NT : 0);                    // epilogue-operand loads per strip
     static_assert(BN / 8 == NWAVE && PIECES == NSLAB && 2 * PIECES + 2 * EST + NL <= 63, "strip geometry: wave w stages row group w of every slab");
-    static_assert(!HAS_RES || MODE == AS_F32, "residual needs the fp32 output mode");
+    static_assert(!HAS_RES || MODE == AS_F32 || MODE == AS_F16, "residual needs a stream output mode (fp32 / fp16)");
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    using res_t = typename std::conditional<MODE == AS_F16, u32x2, f32x4>::type;     // one lane's 4 residual values of a fragment
     static_assert(MT == 2 && NT == 2, "operand lists of the counted waits below");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1335,7 +1420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     // Epilogue operands (bias, residual) are inline-asm loads with counted waits of our own: hipcc's waitcnt pass answers mixed
     // pending loads / stores / LDS-DMA with vmcnt(0), which would drain the weight strips in flight.  HAS_BIAS / HAS_RES are
     // compile-time so that the loads are unconditional (uniform operation counts).
-    auto load_operands = [&](int strip, f32x4 (&bz)[NT], f32x4 (&rz)[MT][NT]) {
+    auto load_operands = [&](int strip, f32x4 (&bz)[NT], res_t (&rz)[MT][NT]) {
         const int n = strip * BN + wn * 32 + 4 * fg;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -1346,15 +1431,18 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if constexpr (HAS_RES)
+                if constexpr (HAS_RES && MODE == AS_F16)
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rz[i][j])
+                                 : "v"(static_cast<const uint16_t*>(p.residual) + (long)(m0 + wm * 16 * MT + 16 * i + fr) * p.ldr + n + 16 * j) : "memory");
+                else if constexpr (HAS_RES)
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rz[i][j])
-                                 : "v"(p.residual + (long)(m0 + wm * 16 * MT + 16 * i + fr) * p.ldr + n + 16 * j) : "memory");
-                else rz[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                                 : "v"(static_cast<const float*>(p.residual) + (long)(m0 + wm * 16 * MT + 16 * i + fr) * p.ldr + n + 16 * j) : "memory");
+                else rz[i][j] = res_t{};
             }
     };
     // alpha, bias, (residual), store: exactly EST vector stores per lane.  WAITN: operations younger than this strip's operand
     // loads that may stay in flight (the "+v" operands order every use of the loaded values behind the wait).
-    auto epilogue = [&](auto WAITN, int strip, f32x4 (&acc)[MT][NT], f32x4 (&bz)[NT], f32x4 (&rz)[MT][NT]) __attribute__((always_inline)) {
+    auto epilogue = [&](auto WAITN, int strip, f32x4 (&acc)[MT][NT], f32x4 (&bz)[NT], res_t (&rz)[MT][NT]) __attribute__((always_inline)) {
         constexpr int waitn = decltype(WAITN)::value;
         if constexpr (HAS_RES)
             asm volatile("s_waitcnt vmcnt(%6)" : "+v"(bz[0]), "+v"(bz[1]), "+v"(rz[0][0]), "+v"(rz[0][1]), "+v"(rz[1][0]), "+v"(rz[1][1]) : "n"(waitn) : "memory");
@@ -1383,6 +1471,16 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
                     if constexpr (HAS_RES) { v4.x += rz[i][j][0]; v4.y += rz[i][j][1]; v4.z += rz[i][j][2]; v4.w += rz[i][j][3]; }
                     *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n + 16 * j) = v4;
                 }
+            } else if constexpr (MODE == AS_F16) {
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float2 ra = unpack_f16x2(rz[i][j][0]), rb = unpack_f16x2(rz[i][j][1]);
+                        o[j][0] += ra.x; o[j][1] += ra.y; o[j][2] += rb.x; o[j][3] += rb.y;
+                    }
+                }
+                store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, make_uint2(pack_f16x2(o[0][0], o[0][1]), pack_f16x2(o[0][2], o[0][3])),
+                                make_uint2(pack_f16x2(o[1][0], o[1][1]), pack_f16x2(o[1][2], o[1][3])));
             } else {
                 uint16_t* crow = static_cast<uint16_t*>(p.C) + (long)m * p.ldc;
                 const uint2 a2 = make_uint2(pack_bf16x2(o[0][0], o[0][1]), pack_bf16x2(o[0][2], o[0][3]));
@@ -1402,7 +1500,8 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     // Top of iteration s: strip s (DMA issued in iteration s-2) must have landed; younger than it are PIECES (DMA s+1) and the
     // stores (and operand loads) of the min(s, 2) epilogues since; the counts below never exceed the true number of younger
     // operations (a smaller count only waits for more).
-    f32x4 acc[MT][NT], bz[NT], rz[MT][NT];
+    f32x4 acc[MT][NT], bz[NT];
+    res_t rz[MT][NT];
     for (int s = 0; s < nstrips; ++s) {
         const int stage = (s + 2) % NST;
         const int ne = s >= 2 ? 2 : s;
@@ -1471,24 +1570,42 @@ inline bool astat_fits(const CcvGemm& p) {
     if (!on || tune_env("CCV_GEMM_RING") != -2 || tune_env("CCV_GEMM_FAMTILE") != -2 || tune_env("CCV_GEMM_SPLIT") > 0) return false;
     return p.gather == 0 && p.taps == 1 && !p.a_f32 && p.K == 320 && p.M % 128 == 0 && p.M / 128 >= 192 && p.M / 128 <= 512 &&
            p.N % 64 == 0 && p.N >= 128 && p.act == 0 && p.bias2 == nullptr && (p.out_f32 || p.residual == nullptr) &&
+           (p.residual == nullptr || (p.res_f16 != 0) == (p.out_f32 == 2)) && (p.out_f32 != 2 || (p.ldc & 7) == 0) &&
            (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
            (p.residual == nullptr || (reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
 }
 template <int MODE>
 int dispatch_astat_mode(const CcvGemm& p, hipStream_t st) {
-    if constexpr (MODE == AS_F32) {
+    if constexpr (MODE == AS_F32 || MODE == AS_F16) {
         if (p.residual) return p.bias ? launch_astat<5, MODE, true, true>(p, st) : launch_astat<5, MODE, false, true>(p, st);
     }
     return p.bias ? launch_astat<5, MODE, true, false>(p, st) : launch_astat<5, MODE, false, false>(p, st);
 }
 inline int dispatch_astat(const CcvGemm& p, hipStream_t st) {
     if (p.geglu) return dispatch_astat_mode<AS_GEGLU>(p, st);
+    if (p.out_f32 == 2) return dispatch_astat_mode<AS_F16>(p, st);
     if (p.out_f32) return dispatch_astat_mode<AS_F32>(p, st);
     const bool wide = (p.ldc & 7) == 0;
     return wide ? dispatch_astat_mode<AS_BF16_WIDE>(p, st) : dispatch_astat_mode<AS_BF16>(p, st);
 }
 
 }  // namespace
+
+// Which operand an XCD's L2 should read only once (block_tile): the larger one.  Unique bytes: the weights [N, taps K] against the
+// source rows of A (a strided convolution reads 4x the output rows, an upsampling one a quarter; every tap re-reads the same rows).
+inline int choose_tile_order(const CcvGemm& p) {
+    static const int forced = [] { const char* e = getenv("CCV_GEMM_ORDER"); return e ? atoi(e) : -1; }();   // A/B aid: 0 / 1 force an order
+    const int live = tune_env("CCV_GEMM_ORDER");
+    if (live == 0 || live == 1) return live;
+    if (forced == 0 || forced == 1) return forced;
+    double src_rows = (double)p.M;
+    if (p.gather == 1 && p.out_h > 0 && p.out_w > 0) src_rows = (double)(p.M / (p.out_h * p.out_w)) * p.src_h * p.src_w;
+    const double a_bytes = src_rows * p.K * (p.a_f32 ? 4.0 : 2.0) * (p.gather == 3 ? p.taps : 1);
+    const double w_bytes = (double)p.N * p.taps * p.K * 2.0;
+    // measured (tools/order_probe.py, cold weights): M-fastest pays only where the weights dwarf the activations -- the M = 512 layers
+    // of the 4x4 latents, -3 ... -18 %; at M = 2048 (weights 2-20x the activations) it costs 1-7 %, at M = 8192 up to 20 %
+    return (w_bytes >= 2.0 * a_bytes && p.M <= 1024) ? 1 : 0;
+}
 
 inline bool plan_ok(const CcvGemm& p) {
     return p.M > 0 && p.N > 0 && p.K > 0 && p.K % BK == 0 && p.taps > 0;
@@ -1569,11 +1686,13 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
             pl = make_plan(p, false);
     }
     p.split_k = pl.split;
+    p.tile_order = choose_tile_order(p);
     const int ring = pl.ring;
     CCV_REQUIRE(p.A && p.W && p.C, CCV_EINVAL, "ccv_gemm: null A/W/C");
     CCV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, CCV_EINVAL, "ccv_gemm: non-positive M/N/K (%d,%d,%d)", p.M, p.N, p.K);
     CCV_REQUIRE(p.K % BK == 0, CCV_ESHAPE, "ccv_gemm: K=%d must be a multiple of 64", p.K);
     CCV_REQUIRE(p.N % 16 == 0, CCV_ESHAPE, "ccv_gemm: N=%d must be a multiple of 16", p.N);
+    CCV_REQUIRE(p.out_f32 >= 0 && p.out_f32 <= 2 && (p.res_f16 == 0 || p.res_f16 == 1), CCV_EINVAL, "ccv_gemm: out_f32 must be 0 / 1 / 2, res_f16 0 / 1");
     CCV_REQUIRE(!p.geglu || (p.N % 32 == 0 && !p.out_f32 && !p.residual && !p.bias2), CCV_ESHAPE,
                 "ccv_gemm: geglu needs N%%32==0, bf16 output, no residual/bias2");
     CCV_REQUIRE(p.lda % 8 == 0 && p.ldc % 4 == 0 && (!p.residual || p.ldr % 4 == 0), CCV_ESHAPE,

@@ -58,22 +58,33 @@ __global__ void unpack_nchw_kernel(const float* in, int ldi, float* out, int c, 
     }
 }
 
-// out[row] = [a[row, 0:ca] | b[row, 0:cb]] in float4 units
-__global__ void concat_rows_kernel(const float4* a, int ca4, const float4* b, int cb4, float4* out, uint2* out16, int64_t rows) {
+// out[row] = [a[row, 0:ca] | b[row, 0:cb]] in units of 4 elements (fp32: float4, fp16: 8 bytes); out16 = its bf16 rounding
+template <int KIND>
+__global__ void concat_rows_kernel(const void* a, int ca4, const void* b, int cb4, void* out, uint2* out16, int64_t rows) {
     const int w = ca4 + cb4;
     const int64_t n = rows * w;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % w);
         const int64_t r = i / w;
-        const float4 v = (c < ca4) ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
-        out[i] = v;
-        if (out16) out16[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        if constexpr (KIND == CCV_F32) {
+            const float4 v = (c < ca4) ? reinterpret_cast<const float4*>(a)[r * ca4 + c] : reinterpret_cast<const float4*>(b)[r * cb4 + (c - ca4)];
+            reinterpret_cast<float4*>(out)[i] = v;
+            if (out16) out16[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        } else {
+            const uint2 u = (c < ca4) ? reinterpret_cast<const uint2*>(a)[r * ca4 + c] : reinterpret_cast<const uint2*>(b)[r * cb4 + (c - ca4)];
+            reinterpret_cast<uint2*>(out)[i] = u;
+            if (out16) {
+                const float2 lo = ccv_unpack_f16x2(u.x), hi = ccv_unpack_f16x2(u.y);
+                out16[i] = make_uint2(pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y));
+            }
+        }
     }
 }
 
-__global__ void cast_bf16_kernel(const float4* x, uint2* y, int64_t n4) {
+template <int KIND>
+__global__ void cast_bf16_kernel(const void* x, uint2* y, int64_t n4) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 v = x[i];
+        const float4 v = ccv_load4<KIND>(x, i);
         y[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
 }
@@ -231,7 +242,10 @@ __global__ void pack_mask_kernel(const uint8_t* mask, uint32_t* bits, uint8_t* f
 // steps, which reproduces the reference's masks bit for bit (tests/golden/geometry_bits.npz: 0 of 10.4 M bits differ at
 // every resolution; plain mul/add or the reverse chain flips 3-19 bits within an ulp of the threshold).
 __device__ __forceinline__ float dot3_chain(float a0, float b0, float a1, float b1, float a2) {
-    return __fadd_rn(__fmaf_rn(a1, b1, __fmul_rn(a0, b0)), a2);
+#pragma clang fp contract(off)
+    const float prod = a0 * b0;                  // rounded product
+    const float acc = __builtin_fmaf(a1, b1, prod);
+    return acc + a2;                             // (HIP's __fmul_rn / __fadd_rn are plain operators, __fsqrt_rn is the NATIVE square root)
 }
 
 __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits, int T, int Tk, int H, int W, float d,
@@ -261,8 +275,8 @@ __global__ void epipolar_bits_kernel(const float* F, uint32_t* bits, uint8_t* fl
                 const float a0 = dot3_chain(f[0], x1, f[1], y1, f[2]);
                 const float a1 = dot3_chain(f[3], x1, f[4], y1, f[5]);
                 const float a2 = dot3_chain(f[6], x1, f[7], y1, f[8]);
-                const float nrm = __fsqrt_rn(__fadd_rn(__fmul_rn(a0, a0), __fmul_rn(a1, a1)));
-                l0 = __fdiv_rn(a0, nrm); l1 = __fdiv_rn(a1, nrm); l2 = __fdiv_rn(a2, nrm);
+                const float nrm = sqrtf(a0 * a0 + a1 * a1);      // correctly rounded square root and divisions (hipcc default); no contraction (pragma above)
+                l0 = a0 / nrm; l1 = a1 / nrm; l2 = a2 / nrm;
                 t2_cached = t2;
             }
             const float x2 = (float)(p2 % W) * d + d / 2.0f - 0.5f;
@@ -346,23 +360,30 @@ extern "C" int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out,
     return CCV_OK;
 }
 
-extern "C" int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, uint16_t* out_bf16, int64_t rows,
-                               void* stream) {
+extern "C" int ccv_concat_rows(const void* a, int32_t ca, const void* b, int32_t cb, void* out, uint16_t* out_bf16, int64_t rows,
+                               int32_t kind, void* stream) {
     CCV_REQUIRE(a && b && out && rows > 0, CCV_EINVAL, "ccv_concat_rows: bad args");
+    CCV_REQUIRE(kind == CCV_F32 || kind == CCV_F16, CCV_EINVAL, "ccv_concat_rows: kind must be 1 (fp32) or 2 (fp16)");
     CCV_REQUIRE(ca % 4 == 0 && cb % 4 == 0 && ca > 0 && cb > 0, CCV_ESHAPE, "ccv_concat_rows: channel counts must be multiples of 4");
     const int64_t n = rows * ((ca + cb) / 4);
-    hipLaunchKernelGGL(concat_rows_kernel, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(a), ca / 4, reinterpret_cast<const float4*>(b), cb / 4,
-                       reinterpret_cast<float4*>(out), reinterpret_cast<uint2*>(out_bf16), rows);
+    if (kind == CCV_F32)
+        hipLaunchKernelGGL(concat_rows_kernel<CCV_F32>, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), a, ca / 4, b, cb / 4, out,
+                           reinterpret_cast<uint2*>(out_bf16), rows);
+    else
+        hipLaunchKernelGGL(concat_rows_kernel<CCV_F16>, grid1d(n), dim3(256), 0, static_cast<hipStream_t>(stream), a, ca / 4, b, cb / 4, out,
+                           reinterpret_cast<uint2*>(out_bf16), rows);
     CCV_LAUNCH_CHECK("ccv_concat_rows");
     return CCV_OK;
 }
 
-extern "C" int ccv_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
+extern "C" int ccv_cast_bf16(const void* x, int32_t x_kind, uint16_t* y, int64_t n, void* stream) {
     CCV_REQUIRE(x && y && n > 0, CCV_EINVAL, "ccv_cast_bf16: bad args");
+    CCV_REQUIRE(x_kind == CCV_F32 || x_kind == CCV_F16, CCV_EINVAL, "ccv_cast_bf16: x_kind must be 1 (fp32) or 2 (fp16)");
     CCV_REQUIRE(n % 4 == 0, CCV_ESHAPE, "ccv_cast_bf16: n must be a multiple of 4");
-    hipLaunchKernelGGL(cast_bf16_kernel, grid1d(n / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float4*>(x), reinterpret_cast<uint2*>(y), n / 4);
+    if (x_kind == CCV_F32)
+        hipLaunchKernelGGL(cast_bf16_kernel<CCV_F32>, grid1d(n / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, reinterpret_cast<uint2*>(y), n / 4);
+    else
+        hipLaunchKernelGGL(cast_bf16_kernel<CCV_F16>, grid1d(n / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, reinterpret_cast<uint2*>(y), n / 4);
     CCV_LAUNCH_CHECK("ccv_cast_bf16");
     return CCV_OK;
 }

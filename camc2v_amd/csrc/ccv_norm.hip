@@ -35,19 +35,14 @@ inline int gn_chunks(int instances, int rows, int C) {
     return c < 1 ? 1 : c;
 }
 
-template <bool X_F32>
-__device__ __forceinline__ float4 load4(const void* x, long idx4) {
-    if (X_F32) return reinterpret_cast<const float4*>(x)[idx4];
-    const uint2 u = reinterpret_cast<const uint2*>(x)[idx4];
-    return make_float4(bf16_to_f32((uint16_t)(u.x & 0xffffu)), bf16_to_f32((uint16_t)(u.x >> 16)),
-                       bf16_to_f32((uint16_t)(u.y & 0xffffu)), bf16_to_f32((uint16_t)(u.y >> 16)));
-}
+template <int XK>      // CCV_BF16 / CCV_F32 / CCV_F16
+__device__ __forceinline__ float4 load4(const void* x, long idx4) { return ccv_load4<XK>(x, idx4); }
 
 // grid (nchunk, instances), gn_threads(C) threads.  Thread (roff, col) owns the 4 channels of float4 column
 // `col` on rows r0+roff, r0+roff+R, ...; GN_UNROLL row loads are issued back to back before any is consumed
 // (the pass is latency-bound otherwise: a chunk is only a few dozen rows).  Its partial sums belong to two
 // fixed channel pairs; the block reduces over roff and over the pairs of each group in a FIXED order.
-template <bool X_F32>
+template <int X_F32>
 __global__ __launch_bounds__(1024) void gn_stats(const void* x, float* partial, int rows_per_instance, int C) {
     __shared__ __attribute__((aligned(16))) float gsm[1024 * 4];  // [R][cols] x (sum01, sq01, sum23, sq23)
     const int inst = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
@@ -91,7 +86,7 @@ __global__ __launch_bounds__(1024) void gn_stats(const void* x, float* partial, 
 // instance to (mean, rstd) per group in a fixed order (4 threads per (group, moment), all loads of a thread in
 // flight together; every block of an instance computes the same bits), which saves a separate finalize launch
 // per GroupNorm; then y = (x-mean)*rstd*gamma+beta [SiLU], GN_UNROLL/2 rows in flight per thread.
-template <bool X_F32>
+template <int X_F32>
 __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, const float* gamma, const float* beta,
                                                  const float* partial, int rows_per_instance, int C, int silu,
                                                  float inv_count, float eps, int npart) {   // npart: partial slots per instance (<= 128)
@@ -169,7 +164,7 @@ __global__ __launch_bounds__(1024) void gn_apply(const void* x, uint16_t* y, con
 // contiguous bytes per row), reads its slice once for the statistics and once more (an L1/L2 hit) to normalise.
 // No partials, no second launch: at these sizes two launches cost more than the bytes they move.  Fixed-order
 // reductions as above (bitwise reproducible).
-template <bool X_F32>
+template <int X_F32>
 __global__ __launch_bounds__(256) void gn_small(const void* x, uint16_t* y, const float* gamma, const float* beta,
                                                 int rows, int C, int gpb, int silu, float inv_count, float eps) {
     __shared__ __attribute__((aligned(16))) float part[256 * 4];
@@ -260,7 +255,7 @@ __global__ __launch_bounds__(256) void gn_small(const void* x, uint16_t* y, cons
 // at least 128 bytes per row and at most 64 columns.  Measured on MI355X (tools/bench_kernels.py norm): the single
 // launch wins while one pass of a workgroup stays under ~24 KiB and there are >= 128 workgroups (frame-wise norms
 // at 8x8 and 4x4 latents: 6-10 us instead of 12-15 us); larger slices are faster through the chunked two-launch path.
-inline int gn_small_gpb(int instances, int rows_per_instance, int C, bool x_f32) {
+inline int gn_small_gpb(int instances, int rows_per_instance, int C, bool x_f32) {   // x_f32: 4-byte elements
     const int cpg = C / GN_GROUPS;
     for (int gpb = 1; gpb <= GN_GROUPS; gpb *= 2) {
         const int span = cpg * gpb;
@@ -278,8 +273,8 @@ inline int gn_small_gpb(int instances, int rows_per_instance, int C, bool x_f32)
 // columns per lane the instance is compiled for (C <= 4 * LPR * LN_MAX4).  The layers here have C = 320 / 640 /
 // 1280 at 32768 / 8192 / 2048 rows: LPR = C/20 keeps 5 float4 (20 registers) per lane at every width, 8 waves per
 // SIMD resident, and the narrow-and-long as well as the wide-and-short activations spread over all CUs.
-template <int LPR, int LN_MAX4, int NR>
-__global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, const float* gamma, const float* beta,
+template <int LPR, int LN_MAX4, int NR, int XK>     // XK: CCV_F32 / CCV_F16 rows
+__global__ __launch_bounds__(256) void ln_kernel(const void* x, uint16_t* y, const float* gamma, const float* beta,
                                                  int rows, int C, float eps, const uint16_t* addend, int addend_rows, uint16_t* y2) {
     // NR rows per lane group: all their loads are in flight together and gamma / beta are fetched once for them
     constexpr int RPB = 256 / LPR * NR;      // rows per block
@@ -291,11 +286,11 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, co
     float4 v[NR][LN_MAX4], gm[LN_MAX4], bt[LN_MAX4];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {           // every load of the kernel is issued here, before the first reduction
-        const float4* xr = reinterpret_cast<const float4*>(x) + (long)(row0 + r < rows ? row0 + r : 0) * cols;
+        const long xr = (long)(row0 + r < rows ? row0 + r : 0) * cols;
 #pragma unroll
         for (int i = 0; i < LN_MAX4; ++i) {
             const int c = l + LPR * i;
-            v[r][i] = c < cols ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[r][i] = c < cols ? ccv_load4<XK>(x, xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
@@ -353,10 +348,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* x, uint16_t* y, co
 }
 
 template <int LPR, int LN_MAX4, int NR>
-void launch_ln(hipStream_t st, const float* x, uint16_t* y, const float* gamma, const float* beta, int rows, int C, float eps,
+void launch_ln(hipStream_t st, const void* x, int kind, uint16_t* y, const float* gamma, const float* beta, int rows, int C, float eps,
                const uint16_t* addend, int ar, uint16_t* y2) {
     constexpr int RPB = 256 / LPR * NR;
-    hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4, NR>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+    if (kind == CCV_F16)
+        hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4, NR, CCV_F16>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+    else
+        hipLaunchKernelGGL((ln_kernel<LPR, LN_MAX4, NR, CCV_F32>), dim3((rows + RPB - 1) / RPB), dim3(256), 0, st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
 }
 
 // fp32 -> fp32 LayerNorm for the small once-per-clip tensors (the adaptor's 4-channel output norm, the Resampler's
@@ -376,6 +374,14 @@ __global__ __launch_bounds__(256) void ln_small_kernel(const float* x, float* y,
     for (int c = lane; c < C; c += 64) y[r * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
 }
 
+// x_f32 of the C ABI is the element kind of x: 0 bf16, 1 fp32, 2 fp16
+#define GN_DISPATCH(KERNEL, kind, ...)                                                  \
+    do {                                                                                \
+        if ((kind) == CCV_F32) hipLaunchKernelGGL(KERNEL<CCV_F32>, __VA_ARGS__);        \
+        else if ((kind) == CCV_F16) hipLaunchKernelGGL(KERNEL<CCV_F16>, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(KERNEL<CCV_BF16>, __VA_ARGS__);                         \
+    } while (0)
+
 }  // namespace
 
 extern "C" int64_t ccv_groupnorm_ws_bytes(int32_t instances, int32_t C) {
@@ -387,19 +393,17 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
                              int32_t instances, int32_t rows_per_instance, int32_t C, float eps, int32_t silu,
                              void* ws, void* stream) {
     CCV_REQUIRE(x && y && gamma && beta && ws, CCV_EINVAL, "ccv_groupnorm: null pointer");
+    CCV_REQUIRE(x_f32 >= 0 && x_f32 <= 2, CCV_EINVAL, "ccv_groupnorm: x_f32 must be 0 (bf16), 1 (fp32) or 2 (fp16)");
     CCV_REQUIRE(instances > 0 && rows_per_instance > 0, CCV_EINVAL, "ccv_groupnorm: non-positive sizes");
     CCV_REQUIRE(instances <= 65535, CCV_ESHAPE, "ccv_groupnorm: too many instances");
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm: C=%d must be a multiple of 64 and <= 4096", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float inv_n = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
     static const bool small_on = [] { const char* e = getenv("CCV_GN_SMALL"); return !(e && e[0] == '0'); }();
-    const int gpb = small_on ? gn_small_gpb(instances, rows_per_instance, C, x_f32 != 0) : 0;
+    const int gpb = small_on ? gn_small_gpb(instances, rows_per_instance, C, x_f32 == CCV_F32) : 0;
     if (gpb > 0) {
         dim3 grid_s(GN_GROUPS / gpb, instances);
-        if (x_f32)
-            hipLaunchKernelGGL(gn_small<true>, grid_s, dim3(256), 0, st, x, y, gamma, beta, rows_per_instance, C, gpb, silu, inv_n, eps);
-        else
-            hipLaunchKernelGGL(gn_small<false>, grid_s, dim3(256), 0, st, x, y, gamma, beta, rows_per_instance, C, gpb, silu, inv_n, eps);
+        GN_DISPATCH(gn_small, x_f32, grid_s, dim3(256), 0, st, x, y, gamma, beta, rows_per_instance, C, gpb, silu, inv_n, eps);
         CCV_LAUNCH_CHECK("ccv_groupnorm(small)");
         return CCV_OK;
     }
@@ -407,16 +411,10 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     const int nthreads = gn_threads(C);
     float* partial = static_cast<float*>(ws);
     dim3 grid(nchunk, instances);
-    if (x_f32)
-        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(nthreads), 0, st, x, partial, rows_per_instance, C);
-    else
-        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(nthreads), 0, st, x, partial, rows_per_instance, C);
+    GN_DISPATCH(gn_stats, x_f32, grid, dim3(nthreads), 0, st, x, partial, rows_per_instance, C);
     CCV_LAUNCH_CHECK("ccv_groupnorm(stats)");
     const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
-    if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
-    else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
+    GN_DISPATCH(gn_apply, x_f32, grid, dim3(nthreads), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
     CCV_LAUNCH_CHECK("ccv_groupnorm(apply)");
     return CCV_OK;
 }
@@ -434,10 +432,7 @@ extern "C" int ccv_groupnorm_stats(const void* x, int32_t x_f32, int32_t instanc
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 4096, CCV_ESHAPE, "ccv_groupnorm_stats: C=%d must be a multiple of 64 and <= 4096", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
-    if (x_f32)
-        hipLaunchKernelGGL(gn_stats<true>, grid, dim3(gn_threads(C)), 0, st, x, static_cast<float*>(ws), rows_per_instance, C);
-    else
-        hipLaunchKernelGGL(gn_stats<false>, grid, dim3(gn_threads(C)), 0, st, x, static_cast<float*>(ws), rows_per_instance, C);
+    GN_DISPATCH(gn_stats, x_f32, grid, dim3(gn_threads(C)), 0, st, x, static_cast<float*>(ws), rows_per_instance, C);
     CCV_LAUNCH_CHECK("ccv_groupnorm_stats");
     return CCV_OK;
 }
@@ -450,10 +445,7 @@ extern "C" int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
     const float* partial = static_cast<const float*>(ws);
-    if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
-    else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
+    GN_DISPATCH(gn_apply, x_f32, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, partial, rows_per_instance, C, silu, inv_count, eps, (int)grid.x);
     CCV_LAUNCH_CHECK("ccv_groupnorm_apply");
     return CCV_OK;
 }
@@ -471,17 +463,15 @@ extern "C" int ccv_groupnorm_apply_parts(const void* x, int32_t x_f32, uint16_t*
     dim3 grid(gn_chunks(instances, rows_per_instance, C), instances);
     const float inv_count = 1.0f / ((float)rows_per_instance * (float)(C / GN_GROUPS));
     const float* pr = static_cast<const float*>(partial);
-    if (x_f32)
-        hipLaunchKernelGGL(gn_apply<true>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, pr, rows_per_instance, C, silu, inv_count, eps, (int)parts);
-    else
-        hipLaunchKernelGGL(gn_apply<false>, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, pr, rows_per_instance, C, silu, inv_count, eps, (int)parts);
+    GN_DISPATCH(gn_apply, x_f32, grid, dim3(gn_threads(C)), 0, st, x, y, gamma, beta, pr, rows_per_instance, C, silu, inv_count, eps, (int)parts);
     CCV_LAUNCH_CHECK("ccv_groupnorm_apply_parts");
     return CCV_OK;
 }
 
-extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, const float* beta,
+extern "C" int ccv_layernorm(const void* x, int32_t x_kind, uint16_t* y, const float* gamma, const float* beta,
                              int32_t rows, int32_t C, float eps, const uint16_t* addend, int32_t addend_rows, uint16_t* y2, void* stream) {
     CCV_REQUIRE(x && y && gamma && beta, CCV_EINVAL, "ccv_layernorm: null pointer");
+    CCV_REQUIRE(x_kind == CCV_F32 || x_kind == CCV_F16, CCV_EINVAL, "ccv_layernorm: x_kind must be 1 (fp32) or 2 (fp16)");
     CCV_REQUIRE(rows > 0, CCV_EINVAL, "ccv_layernorm: rows=%d", rows);
     CCV_REQUIRE(C % 64 == 0 && C > 0 && C <= 2048, CCV_ESHAPE, "ccv_layernorm: C=%d must be a multiple of 64 and <= 2048", C);
     CCV_REQUIRE((addend == nullptr) == (y2 == nullptr), CCV_EINVAL, "ccv_layernorm: addend and y2 go together");
@@ -492,13 +482,13 @@ extern "C" int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, co
     static const int nr_env = [] { const char* e = getenv("CCV_LN_ROWS"); return e ? atoi(e) : 2; }();
     const bool two = nr_env == 2 && (long)rows * (C <= 320 ? 16 : C <= 640 ? 32 : 64) >= 2l * 256 * 1024;
     if (C <= 320)
-        two ? launch_ln<16, 5, 2>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2) : launch_ln<16, 5, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        two ? launch_ln<16, 5, 2>(st, x, x_kind, y, gamma, beta, rows, C, eps, addend, ar, y2) : launch_ln<16, 5, 1>(st, x, x_kind, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else if (C <= 640)
-        two ? launch_ln<32, 5, 2>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2) : launch_ln<32, 5, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        two ? launch_ln<32, 5, 2>(st, x, x_kind, y, gamma, beta, rows, C, eps, addend, ar, y2) : launch_ln<32, 5, 1>(st, x, x_kind, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else if (C <= 1280)
-        launch_ln<64, 5, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<64, 5, 1>(st, x, x_kind, y, gamma, beta, rows, C, eps, addend, ar, y2);
     else
-        launch_ln<64, 8, 1>(st, x, y, gamma, beta, rows, C, eps, addend, ar, y2);
+        launch_ln<64, 8, 1>(st, x, x_kind, y, gamma, beta, rows, C, eps, addend, ar, y2);
     CCV_LAUNCH_CHECK("ccv_layernorm");
     return CCV_OK;
 }

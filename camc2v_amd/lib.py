@@ -24,6 +24,7 @@ class CcvGemm(C.Structure):
         ("alpha", f32),
         ("ws", vp), ("ws_bytes", i64), ("split_k", i32),
         ("gn_partial", vp), ("gn_rows", i32), ("gn_slots", i32),
+        ("res_f16", i32), ("tile_order", i32),
     ]
 
 
@@ -67,10 +68,10 @@ SIGNATURES = {
     "ccv_groupnorm_stats": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "ccv_groupnorm_apply": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, f32, vp]),
     "ccv_groupnorm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),
-    "ccv_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, i32, vp, vp]),
+    "ccv_layernorm": (i32, [vp, i32, vp, vp, vp, i32, i32, f32, vp, i32, vp, vp]),
     "ccv_pack_nchw_to_rows": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "ccv_unpack_rows_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
-    "ccv_concat_rows": (i32, [vp, i32, vp, i32, vp, vp, i64, vp]),
+    "ccv_concat_rows": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, vp]),
     "ccv_attn_small_fwd": (i32, [C.POINTER(CcvAttn), i32, vp]),
     "ccv_ray_condition": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "ccv_pixel_unshuffle_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -80,7 +81,7 @@ SIGNATURES = {
     "ccv_avgpool2_rows": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ccv_layernorm_small": (i32, [vp, vp, vp, vp, i64, i32, i64, f32, vp]),
     "ccv_softmax_rows": (i32, [vp, vp, i32, i32, i64, i64, vp]),
-    "ccv_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "ccv_cast_bf16": (i32, [vp, i32, vp, i64, vp]),
     "ccv_nchw_to_rows_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ccv_timestep_embedding": (i32, [vp, vp, i32, i32, vp]),
     "ccv_add_silu_bf16": (i32, [vp, vp, vp, i64, vp]),

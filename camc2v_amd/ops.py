@@ -14,6 +14,14 @@ from .lib import CcvAttn, CcvError, CcvGemm, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+F16 = torch.float16      # the residual stream's hand-off format between UNet blocks (arithmetic stays fp32 inside the kernels)
+_KIND = {BF16: 0, F32: 1, F16: 2}      # element-kind codes of the C ABI (include/ccv.h)
+
+
+def _kind(t, allowed, what):
+    if t.dtype not in allowed:
+        raise CcvError(f"{what}: dtype {t.dtype} not supported (expected one of {[str(d) for d in allowed]})")
+    return _KIND[t.dtype]
 
 GATHER_LINEAR, GATHER_CONV3X3, GATHER_TCONV3, GATHER_SEGMENTS = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
@@ -53,11 +61,14 @@ def set_streams_in_flight(n):
 
 def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
          residual=None, act=ACT_NONE, geglu=False, out_f32=False, out=None, gather=GATHER_LINEAR,
-         conv=None, tconv=None, seg_rows=None, alpha=1.0, debug_ws=None, gn_rows=None):
+         conv=None, tconv=None, seg_rows=None, alpha=1.0, debug_ws=None, gn_rows=None, out_dtype=None):
     """out[m, n] = epilogue(sum_tap gather(a) @ w_tap^T).  See include/ccv.h (ccv_gemm).
     gn_rows: the output feeds a GroupNorm(32) whose instances are `gn_rows` consecutive rows; the call then returns
     (out, stats) with stats = GroupNorm statistics produced by the epilogue (hand them to ``groupnorm(..., stats=)``) or None when
     the kernel this problem runs on cannot produce them (``groupnorm`` then computes its own).
+
+    out_dtype: torch.bfloat16 (default), torch.float32 (= out_f32=True) or torch.float16 (the stream's hand-off format);
+    residual: fp32 or fp16 [M, >= N].
 
     a: [rows, lda] bf16 or fp32 (2-D, last dim contiguous); w: [N, taps*K] bf16.
     conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw);
@@ -74,8 +85,12 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         raise CcvError(f"gemm: W has {w.shape[1]} columns, expected taps*K = {taps}*{K}")
     M = m if m is not None else a.shape[0]
     n_cols = N // 2 if geglu else N
+    if out_dtype is None:
+        out_dtype = F32 if out_f32 else BF16
+    elif out_dtype not in _KIND:
+        raise CcvError(f"gemm: out_dtype {out_dtype} not supported")
     if out is None:
-        out = torch.empty((M, n_cols), dtype=F32 if out_f32 else BF16, device=a.device)
+        out = torch.empty((M, n_cols), dtype=out_dtype, device=a.device)
     p = CcvGemm()
     p.A, p.W, p.C = _ptr(a), _ptr(w), _ptr(out)
     p.bias, p.bias2, p.residual = _ptr(bias), _ptr(bias2), _ptr(residual)
@@ -92,9 +107,11 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         raise CcvError(f"gemm: unsupported A dtype {a.dtype}")
     if bias is not None and (bias.dtype != F32 or bias.numel() < N):
         raise CcvError("gemm: bias must be fp32 [N]")
-    if residual is not None and residual.dtype != F32:
-        raise CcvError("gemm: residual must be fp32")
-    if out.dtype != (F32 if out_f32 else BF16):
+    if residual is not None:
+        p.res_f16 = int(_kind(residual, (F32, F16), "gemm: residual") == 2)
+        if residual.stride(1) != 1:
+            raise CcvError("gemm: residual must have a contiguous last dim")
+    if out.dtype != out_dtype:
         raise CcvError("gemm: out dtype mismatch")
     p.gather = gather
     # the kernels trust M and the gather geometry: check them against the tensors here, on the host
@@ -132,7 +149,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         if not ok:
             raise CcvError(f"gemm: bias2 must hold {nb2} fp32 rows of >= {N} columns, ldb2 = {ldb2} apart")
     p.rows_per_batch = rows_per_batch
-    p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), int(out_f32), alpha
+    p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), {BF16: 0, F32: 1, F16: 2}[out_dtype], alpha
     stats = None
     if gn_rows:
         slots = lib().ccv_gemm_gn_slots(C.byref(p), gn_rows)
@@ -310,22 +327,23 @@ def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wa
 # norms
 # ---------------------------------------------------------------------------------------
 def groupnorm(x, gamma, beta, *, instances, eps, silu, stats=None):
-    """x [rows, C] fp32|bf16 -> bf16; statistics per (instance, group of C/32 channels).  stats: what ``gemm(..., gn_rows=)``
+    """x [rows, C] fp32|fp16|bf16 -> bf16; statistics per (instance, group of C/32 channels).  stats: what ``gemm(..., gn_rows=)``
     returned for the GEMM that produced x (the statistics pass is skipped), or None."""
     _dev(x, gamma, beta)
     rows, Cc = _rows(x)
     if rows % instances:
         raise CcvError("groupnorm: rows not divisible by instances")
+    xk = _kind(x, (F32, F16, BF16), "groupnorm")
     y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
     if stats is not None:
         part, gn_rows = stats
         if gn_rows * instances != rows or part.shape[0] != instances or part.shape[2] != 64 or part.dtype != F32 or not part.is_contiguous():
             raise CcvError(f"groupnorm: stats were produced for instances of {gn_rows} rows, x has {rows} rows in {instances} instances")
-        check(lib().ccv_groupnorm_apply_parts(_ptr(x), int(x.dtype == F32), _ptr(y), _ptr(gamma), _ptr(beta), instances, gn_rows, Cc, eps,
+        check(lib().ccv_groupnorm_apply_parts(_ptr(x), xk, _ptr(y), _ptr(gamma), _ptr(beta), instances, gn_rows, Cc, eps,
                                               int(silu), _ptr(part), part.shape[1], _stream()), "ccv_groupnorm_apply_parts")
         return y
     ws = torch.empty(lib().ccv_groupnorm_ws_bytes(instances, Cc), dtype=torch.uint8, device=x.device)
-    check(lib().ccv_groupnorm(_ptr(x), int(x.dtype == F32), _ptr(y), _ptr(gamma), _ptr(beta), instances,
+    check(lib().ccv_groupnorm(_ptr(x), xk, _ptr(y), _ptr(gamma), _ptr(beta), instances,
                               rows // instances, Cc, eps, int(silu), _ptr(ws), _stream()), "ccv_groupnorm")
     return y
 
@@ -341,7 +359,7 @@ def groupnorm_sharded(x, gamma, beta, *, instances, eps, silu, reduce_sums, tota
     rpi = rows // instances
     nchunk = lib().ccv_groupnorm_chunks(instances, rpi, Cc)
     ws = torch.empty(lib().ccv_groupnorm_ws_bytes(instances, Cc) // 4, dtype=F32, device=x.device)
-    xf = int(x.dtype == F32)
+    xf = _kind(x, (F32, F16, BF16), "groupnorm_sharded")
     check(lib().ccv_groupnorm_stats(_ptr(x), xf, instances, rpi, Cc, _ptr(ws), _stream()), "ccv_groupnorm_stats")
     part = ws[:instances * nchunk * 64].view(instances, nchunk, 64)
     sums = part.sum(1)
@@ -356,10 +374,9 @@ def groupnorm_sharded(x, gamma, beta, *, instances, eps, silu, reduce_sums, tota
 
 
 def layernorm(x, gamma, beta, *, eps=1e-5, addend=None, out2=None):
-    """x [rows, C] fp32 -> bf16 (and y + addend[r % addend_rows] when addend is given; `out2`: where that second output goes)."""
+    """x [rows, C] fp32|fp16 -> bf16 (and y + addend[r % addend_rows] when addend is given; `out2`: where that second output goes)."""
     _dev(x, gamma, beta, addend)
-    if x.dtype != F32:
-        raise CcvError("layernorm: x must be fp32 (the residual stream)")
+    xk = _kind(x, (F32, F16), "layernorm (the residual stream)")
     rows, Cc = _rows(x)
     y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
     y2 = None
@@ -371,7 +388,7 @@ def layernorm(x, gamma, beta, *, eps=1e-5, addend=None, out2=None):
         y2 = torch.empty_like(y) if out2 is None else out2
         if y2.dtype != BF16 or not y2.is_contiguous() or tuple(y2.shape) != tuple(y.shape):
             raise CcvError("layernorm: out2 must be contiguous bf16 shaped like the output")
-    check(lib().ccv_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _ptr(addend), arows,
+    check(lib().ccv_layernorm(_ptr(x), xk, _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _ptr(addend), arows,
                               _ptr(y2), _stream()), "ccv_layernorm")
     return (y, y2) if addend is not None else y
 
@@ -403,15 +420,16 @@ def unpack_rows_to_nchw(rows, c, b, t, h, w):
 
 
 def concat_rows(a, b, with_bf16=False):
-    """[rows, ca] ++ [rows, cb] fp32; with_bf16 also returns the bf16 rounding of the result (out, out16)."""
+    """[rows, ca] ++ [rows, cb], both fp32 or both fp16; with_bf16 also returns the bf16 rounding of the result (out, out16)."""
     _dev(a, b)
     rows, ca = _rows(a)
     rows_b, cb = _rows(b)
-    if rows != rows_b or a.dtype != F32 or b.dtype != F32:
-        raise CcvError("concat_rows: fp32 inputs with equal row counts expected")
-    out = torch.empty((rows, ca + cb), dtype=F32, device=a.device)
+    kind = _kind(a, (F32, F16), "concat_rows")
+    if rows != rows_b or b.dtype != a.dtype:
+        raise CcvError("concat_rows: inputs of one dtype with equal row counts expected")
+    out = torch.empty((rows, ca + cb), dtype=a.dtype, device=a.device)
     out16 = torch.empty((rows, ca + cb), dtype=BF16, device=a.device) if with_bf16 else None
-    check(lib().ccv_concat_rows(_ptr(a), ca, _ptr(b), cb, _ptr(out), _ptr(out16), rows, _stream()), "ccv_concat_rows")
+    check(lib().ccv_concat_rows(_ptr(a), ca, _ptr(b), cb, _ptr(out), _ptr(out16), rows, kind, _stream()), "ccv_concat_rows")
     return (out, out16) if with_bf16 else out
 
 
@@ -523,10 +541,9 @@ def softmax_rows(x):
 def cast_bf16(x):
     _dev(x)
     x = x.contiguous()
-    if x.dtype != F32:
-        raise CcvError("cast_bf16: fp32 input expected")
+    kind = _kind(x, (F32, F16), "cast_bf16")
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
-    check(lib().ccv_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "ccv_cast_bf16")
+    check(lib().ccv_cast_bf16(_ptr(x), kind, _ptr(y), x.numel(), _stream()), "ccv_cast_bf16")
     return y
 
 

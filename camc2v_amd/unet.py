@@ -9,7 +9,7 @@ fp32 parameters; every forward runs hand-written HIP kernels through ``camc2v_am
 
   * activations stay token-major ``[(b t h w), C]`` for the whole network (no NCHW<->token
     transposes: spatial, temporal and epipolar attention only differ in the strides handed to
-    the attention kernel); the residual stream is fp32, GEMM operands bf16;
+    the attention kernel); the residual stream is fp16 (fp32 arithmetic in every epilogue and norm), GEMM operands bf16;
   * GroupNorm+SiLU -> bf16, then implicit-GEMM conv3x3 / temporal conv with bias, time-embedding
     add and residual fused into the epilogue; LayerNorm (+Pluecker add) -> fused QKV GEMM ->
     attention -> out-projection accumulating into the stream; GEGLU fused into its GEMM;
@@ -37,6 +37,11 @@ FUSE_CAMERA_PROJECTIONS = __import__("os").environ.get("CCV_FUSE_CAM", "1") != "
 FP8_EPIPOLAR = __import__("os").environ.get("CCV_ATTN_FP8", "0") == "1"
 FP8_EPIPOLAR_MIN_TOKENS = 2048
 TEXT_LEN = 77  # CrossAttention.text_context_len (reference attention.py:49)
+# The residual stream between layers: fp16 -- what the reference itself carries between blocks under its fp16 autocast
+# (main/trainer.py:193: conv / linear outputs are fp16, only the norms compute in fp32) -- with fp32 arithmetic inside every
+# epilogue and norm.  Half the bytes of every GroupNorm / LayerNorm read and residual epilogue of the fp32 stream of rounds 1-2.
+# CCV_STREAM=f32 (A/B aid) restores the fp32 stream; every kernel takes both.
+STREAM = torch.float32 if os.environ.get("CCV_STREAM", "f16") == "f32" else torch.float16
 
 
 def _zero(module):
@@ -159,7 +164,7 @@ class CrossAttention(nn.Module, _Prepared):
         s = (hw * ld, 0, ld)
         o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b * g.t, inner=1, H=H, Lq=hw, Lk=hw,
                           q_str=s, k_str=s, v_str=s, scale=self.scale)
-        ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+        ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_dtype=stream.dtype, out=stream)
 
     # ---- self attention over the frames of each pixel; activations stay token-major -------------
     def temporal_attend(self, n, g, out=None):
@@ -183,7 +188,7 @@ class CrossAttention(nn.Module, _Prepared):
 
     def self_attn_temporal(self, n, stream, g):
         pk = self._pk()
-        ops.gemm(self.temporal_attend(n, g), pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+        ops.gemm(self.temporal_attend(n, g), pk["w_o"], bias=pk["b_o"], residual=stream, out_dtype=stream.dtype, out=stream)
 
     # ---- cross attention against cached context projections --------------------------------------
     def project_context(self, text_rows, img_rows):
@@ -217,7 +222,7 @@ class CrossAttention(nn.Module, _Prepared):
             ops.attention(qs, kv_t, kv_t[:, C:], B=nc * g.t, inner=g.t, H=H, Lq=hw, Lk=TEXT_LEN,
                           q_str=(rows_per_clip * C, hw * C, C), k_str=st_t, v_str=st_t,
                           out=os_, o_str=(rows_per_clip * C, hw * C, C), scale=self.scale, **kw)
-        ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+        ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_dtype=stream.dtype, out=stream)
 
     # ---- reference-shaped entry point (module level parity tests) ---------------------------------
     def forward(self, x, context=None, mask=None):
@@ -270,7 +275,7 @@ class FeedForward(nn.Module, _Prepared):
         hidden = ops.gemm(n, pk["w1"], bias=pk["b1"], geglu=True)
         if final:
             return ops.gemm(hidden, pk["w2"], bias=pk["b2"], residual=stream)
-        ops.gemm(hidden, pk["w2"], bias=pk["b2"], residual=stream, out_f32=True, out=stream)
+        ops.gemm(hidden, pk["w2"], bias=pk["b2"], residual=stream, out_dtype=stream.dtype, out=stream)
         return stream
 
     def forward(self, x):
@@ -337,7 +342,7 @@ class Epipolar(nn.Module, _Prepared):
     def run(self, src, stream, g, packed_mask):
         """src [(b t hw), C] bf16 (= LN(x) + Pluecker rows); packed_mask (bits, flags, nb) or None."""
         pk = self._pk()
-        ops.gemm(self.attend(src, g, packed_mask), pk["w_o"], bias=pk["b_o"], residual=stream, out_f32=True, out=stream)
+        ops.gemm(self.attend(src, g, packed_mask), pk["w_o"], bias=pk["b_o"], residual=stream, out_dtype=stream.dtype, out=stream)
 
     def attend(self, src, g, packed_mask, out=None):
         """The masked attention over all T*H*W tokens, before the output projection: bf16 [(b t hw), C] (into `out`)."""
@@ -442,7 +447,7 @@ class BasicTransformerBlock(nn.Module, _Prepared):
                 self.attn1.temporal_attend(n, g, out=stack[0])
                 self.epipolar.attend(stack[1], g, cam.get("mask"), out=stack[2])
                 ops.gemm(stack.view(3 * rows, C), pk["w_cam"], k=C, taps=3, m=rows, gather=ops.GATHER_SEGMENTS, seg_rows=rows,
-                         bias=pk["b_cam"], residual=stream, out_f32=True, out=stream)
+                         bias=pk["b_cam"], residual=stream, out_dtype=stream.dtype, out=stream)
                 self.attn2.self_attn_temporal(self._ln(2, stream), stream, g)
                 return self.ff.run(self._ln(3, stream), stream, final)
             if prow is not None:
@@ -453,7 +458,7 @@ class BasicTransformerBlock(nn.Module, _Prepared):
             if main:
                 self.attn1.self_attn_temporal(n, stream, g)
             if prow is not None and "w_pl" in pk:
-                ops.gemm(src, pk["w_pl"], bias=pk["b_pl"], residual=target, out_f32=True, out=target)
+                ops.gemm(src, pk["w_pl"], bias=pk["b_pl"], residual=target, out_dtype=target.dtype, out=target)
             if hasattr(self, "epipolar"):
                 self.epipolar.run(src, target, g, cam.get("mask"))
             if not main:
@@ -493,11 +498,11 @@ class SpatialTransformer(nn.Module, _Prepared):
     def forward_rows(self, x, g, ctx_groups_per_block):
         pk = self._pk()
         n = ops.groupnorm(x, pk["gn_g"], pk["gn_b"], instances=g.b * g.t, eps=self.norm.eps, silu=False)
-        s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_f32=True)
+        s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_dtype=x.dtype)
         last = len(self.transformer_blocks) - 1
         for i, (blk, groups) in enumerate(zip(self.transformer_blocks, ctx_groups_per_block)):
             s = blk.run_spatial(s, g, groups, final=(i == last))
-        return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_f32=True)
+        return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_dtype=x.dtype)
 
 
 class TemporalTransformer(nn.Module, _Prepared):
@@ -530,11 +535,11 @@ class TemporalTransformer(nn.Module, _Prepared):
     def forward_rows(self, x, g, cam):
         pk = self._pk()
         n = _clip_groupnorm(x, pk["gn_g"], pk["gn_b"], g, self.norm.eps, False)
-        s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_f32=True)
+        s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_dtype=x.dtype)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             s = blk.run_temporal(s, g, cam, final=(i == last))
-        return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_f32=True)
+        return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_dtype=x.dtype)
 
 
 # =============================================================================================
@@ -562,8 +567,9 @@ class Downsample(nn.Module, _Prepared):
     def forward_rows(self, x, g):
         pk = self._pk()
         oh, ow = (g.h + 1) // 2, (g.w + 1) // 2
-        x = ops.cast_bf16(x)   # bf16 operand: the conv then runs on the LDS-DMA kernel (fp32 A needs register staging)
-        y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_f32=True,
+        sd = x.dtype
+        x = ops.cast_bf16(x)   # bf16 operand: the conv then runs on the LDS-DMA kernel (a stream-typed A needs register staging)
+        y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_dtype=sd,
                      gather=ops.GATHER_CONV3X3, conv=(oh, ow, g.h, g.w, 2, 0))
         return y, Geom(g.b, g.t, oh, ow)
 
@@ -582,8 +588,9 @@ class Upsample(nn.Module, _Prepared):
     def forward_rows(self, x, g):
         pk = self._pk()
         oh, ow = 2 * g.h, 2 * g.w   # nearest 2x is folded into the conv's gather
+        sd = x.dtype
         x = ops.cast_bf16(x)
-        y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_f32=True,
+        y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_dtype=sd,
                      gather=ops.GATHER_CONV3X3, conv=(oh, ow, g.h, g.w, 1, 1))
         return y, Geom(g.b, g.t, oh, ow)
 
@@ -626,14 +633,15 @@ class TemporalConvBlock(nn.Module, _Prepared):
             if fc is not None:     # frames sharded over ranks: the neighbours' edge frames in front of / behind the local ones
                 hw = g.h * g.w
                 ze = fc.with_halo(z, g.b, hw)
-                he = ops.gemm(ze, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t + 2, hw), out_f32=last)
+                he = ops.gemm(ze, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t + 2, hw),
+                              out_dtype=torch.float32 if last else ops.BF16)
                 h = fc.inner(he, g.b, hw)
                 if last:
-                    h = h + x
+                    h = (h + x.float()).to(x.dtype)
                 continue
             if last:
                 h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w), residual=x,
-                             out_f32=True)
+                             out_dtype=x.dtype)
             elif CLIP_NORM_STATS_FROM_EPILOGUE:
                 h, st = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w),
                                  gn_rows=g.t * g.h * g.w)
@@ -686,7 +694,7 @@ class ResBlock(TimestepBlock, _Prepared):
         return pk
 
     def forward_rows(self, x, emb_all, g, x_bf16=None):
-        """x fp32 [(b t h w), Cin]; emb_all fp32 [b, sum Cout] (all ResBlock emb projections in one GEMM);
+        """x [(b t h w), Cin] in the stream dtype; emb_all fp32 [b, sum Cout] (all ResBlock emb projections in one GEMM);
         x_bf16: optional bf16 rounding of x (what the skip convolution's operand load would produce anyway)."""
         pk = self._pk()
         cin, cout = self.channels, self.out_channels
@@ -702,12 +710,14 @@ class ResBlock(TimestepBlock, _Prepared):
         h = ops.groupnorm(h, pk["g2"], pk["b2"], instances=g.b * g.t, eps=1e-5, silu=True, stats=st)
         skip = x
         if "ws" in pk:
-            xs = x_bf16 if x_bf16 is not None else x
+            # operand of the skip convolution: the bf16 rounding the caller already made, else the fp32 stream itself (register-staged
+            # kernel, converts on load) or a bf16 copy of the fp16 stream
+            xs = x_bf16 if x_bf16 is not None else (x if x.dtype == torch.float32 else ops.cast_bf16(x))
             if pk["skip_taps"] == 9:
-                skip = ops.gemm(xs, pk["ws"], k=cin, taps=9, bias=pk["bs"], out_f32=True, gather=ops.GATHER_CONV3X3, conv=conv)
+                skip = ops.gemm(xs, pk["ws"], k=cin, taps=9, bias=pk["bs"], out_dtype=x.dtype, gather=ops.GATHER_CONV3X3, conv=conv)
             else:
-                skip = ops.gemm(xs, pk["ws"], bias=pk["bs"], out_f32=True)
-        out = ops.gemm(h, pk["w2"], k=cout, taps=9, bias=pk["cb2"], residual=skip, out_f32=True,
+                skip = ops.gemm(xs, pk["ws"], bias=pk["bs"], out_dtype=x.dtype)
+        out = ops.gemm(h, pk["w2"], k=cout, taps=9, bias=pk["cb2"], residual=skip, out_dtype=skip.dtype,
                        gather=ops.GATHER_CONV3X3, conv=conv)
         if self.use_temporal_conv:
             out = self.temopral_conv.forward_rows(out, g)
@@ -1137,7 +1147,7 @@ class UNetModel(nn.Module, _Prepared):
 
         # -- input conv on the zero-padded 64-channel fp32 rows -------------------------------------------
         rows = ops.pack_nchw_to_rows(x, None, ldo=pk["cin_pad"])
-        h = ops.gemm(rows, pk["w_in"], k=pk["cin_pad"], taps=9, bias=pk["b_in"], out_f32=True,
+        h = ops.gemm(rows, pk["w_in"], k=pk["cin_pad"], taps=9, bias=pk["b_in"], out_dtype=STREAM,
                      gather=ops.GATHER_CONV3X3, conv=(H, W, H, W, 1, 0))
         if self.addition_attention:
             h = self.init_attn[0].forward_rows(h, g, None)  # never camera conditioned (modified_forwards.py:80-81)

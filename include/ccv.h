@@ -21,7 +21,7 @@
  * xformers or F.scaled_dot_product_attention.
  *
  * Layouts: activations are token-major ("NHWC"): a tensor [b, t, h, w, C] is a row-major
- * matrix [rows = b*t*h*w, C].  The residual stream is fp32, GEMM/attention operands bf16
+ * matrix [rows = b*t*h*w, C].  The residual stream is fp16 (UNet; fp32 is supported too), GEMM/attention operands bf16
  * (raw uint16 bit patterns), statistics and accumulation fp32.
  */
 #ifndef CCV_H_
@@ -76,7 +76,7 @@ const char* ccv_last_error(void);
  * out: v = alpha*acc + bias[n] + bias2[(m / rows_per_batch)*ldb2 + n]; v = act(v);
  *      geglu: W rows are interleaved in 16-row blocks (value block, gate block); the output
  *             has N/2 columns = value * gelu_erf(gate);
- *      v += residual[m][n] (fp32); store bf16 or fp32 at C[m*ldc + n].
+ *      v += residual[m][n] (fp32, or fp16 with res_f16); store bf16, fp32 or fp16 (out_f32 = 0 / 1 / 2) at C[m*ldc + n].
  * Constraints: K % 64 == 0, N % 16 == 0 (N % 32 for geglu), lda/ldc/ldr % 8 == 0.
  * ------------------------------------------------------------------------------------ */
 typedef struct CcvGemm {
@@ -85,7 +85,7 @@ typedef struct CcvGemm {
     void* C;
     const float* bias;     /* [N] or NULL */
     const float* bias2;    /* [M / rows_per_batch, N] or NULL */
-    const float* residual; /* [M, ldr] fp32 or NULL (may alias C when out_f32) */
+    const void* residual;  /* [M, ldr] fp32 (fp16 when res_f16) or NULL (may alias C when the output has the same type) */
     int32_t M, N, K, taps;
     int32_t lda, ldc, ldr, ldb2; /* ldb2: row stride of bias2 (>= N) */
     int32_t a_f32;          /* 0: A is bf16, 1: A is fp32 (converted on load) */
@@ -101,7 +101,7 @@ typedef struct CcvGemm {
     int32_t rows_per_batch; /* bias2 row = m / rows_per_batch */
     int32_t act;            /* 0 none, 1 SiLU, 2 GELU(erf), 3 ReLU */
     int32_t geglu;          /* 0/1 */
-    int32_t out_f32;        /* 0: C is bf16, 1: C is fp32 */
+    int32_t out_f32;        /* 0: C is bf16, 1: C is fp32, 2: C is fp16 */
     float alpha;
     void* ws;               /* optional split-K workspace (ccv_gemm_ws_bytes) or NULL */
     int64_t ws_bytes;
@@ -113,6 +113,9 @@ typedef struct CcvGemm {
      * ccv_gemm_gn_slots() returns for this problem (bf16 output, no split-K, tile rows dividing gn_rows). */
     float* gn_partial;
     int32_t gn_rows, gn_slots;
+    int32_t res_f16;        /* 0: residual is fp32, 1: residual is fp16 (the residual stream's hand-off format between blocks:
+                             * what the reference carries under torch.autocast, main/trainer.py:193; arithmetic stays fp32) */
+    int32_t tile_order;     /* set by the library; callers leave it 0 (0: an XCD walks output tiles N-fastest, 1: M-fastest) */
 } CcvGemm;
 /* Workspace the library would like for this problem (0 = none).  Long-K, few-tile problems (the 4x4 and 8x8
  * latent layers) are split along K over extra workgroups when the workspace is provided; without it the
@@ -197,7 +200,7 @@ int ccv_attn_small_fwd(const CcvAttn* p, int32_t head_dim, void* stream);
  * GroupNorm(32 groups) (+SiLU) over token-major activations, fp32 statistics.
  * Replaces GroupNormSpecific / nn.GroupNorm + nn.SiLU (lvdm/basics.py:78-91,
  * openaimodel3d.py:151-153,175-177,255-266,561-563; attention.py:273,343).
- *   x  : [instances*rows_per_instance, C] fp32 (x_f32) or bf16
+ *   x  : [instances*rows_per_instance, C]; x_f32 = element kind: 0 bf16, 1 fp32, 2 fp16 (the residual stream's hand-off format)
  *   y  : same shape, bf16
  *   ws : workspace, ccv_groupnorm_ws_bytes(instances, C) bytes
  * An instance is the set of rows that share statistics: one frame (h*w rows) for 4-D
@@ -222,11 +225,11 @@ int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, const float* 
 int ccv_groupnorm_apply_parts(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
                               int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* partial, int32_t parts, void* stream);
 
-/* LayerNorm over the last dim, fp32 in -> bf16 out; optional second output
+/* LayerNorm over the last dim, fp32 (x_kind 1) or fp16 (x_kind 2) in -> bf16 out, fp32 statistics; optional second output
  * y2[r] = y[r] + addend[r % addend_rows] (bf16 [addend_rows, C]) used for the Pluecker-feature add `normed_x + pluker_embedding_features`
  * (model/modules/modified_forwards.py:508-515).  Replaces nn.LayerNorm (attention.py:232-234).
  * Constraint: C % 64 == 0, C <= 2048. */
-int ccv_layernorm(const float* x, uint16_t* y, const float* gamma, const float* beta,
+int ccv_layernorm(const void* x, int32_t x_kind, uint16_t* y, const float* gamma, const float* beta,
                   int32_t rows, int32_t C, float eps,
                   const uint16_t* addend, int32_t addend_rows, uint16_t* y2, void* stream);
 /* LayerNorm fp32 in (row stride ldx) -> fp32 out [rows, C], any C, one wave per row: the output norms of the
@@ -246,10 +249,11 @@ int ccv_pack_nchw_to_rows(const float* x, int32_t c1, const float* x2, int32_t c
 /* '(b t) c h w -> b c t h w' of the first c columns (openaimodel3d.py:623): in [rows, ldi] fp32. */
 int ccv_unpack_rows_to_nchw(const float* in, int32_t ldi, float* out, int32_t c,
                             int32_t b, int32_t t, int32_t hw, void* stream);
-/* torch.cat([h, skip], dim=1) on token-major fp32 rows (openaimodel3d.py:617); out_bf16 (or NULL) receives the
- * same rows rounded to bf16, the form the ResBlock's 1x1 skip convolution consumes as a GEMM operand. */
-int ccv_concat_rows(const float* a, int32_t ca, const float* b, int32_t cb, float* out, uint16_t* out_bf16,
-                    int64_t rows, void* stream);
+/* torch.cat([h, skip], dim=1) on token-major rows of the residual stream (openaimodel3d.py:617), kind 1 = fp32 / 2 = fp16 (a, b
+ * and out alike); out_bf16 (or NULL) receives the same rows rounded to bf16, the form the ResBlock's 1x1 skip convolution
+ * consumes as a GEMM operand. */
+int ccv_concat_rows(const void* a, int32_t ca, const void* b, int32_t cb, void* out, uint16_t* out_bf16,
+                    int64_t rows, int32_t kind, void* stream);
 /* Once-per-clip camera feeders (model/base.py:112-174, model/modules/camera_pose_encoder.py:361-376).
  * ccv_ray_condition: K [B,V,3,3], c2w [B,V,4,4] fp32 -> out [B,6,V,H,W] fp32, (o x d | d) when plucker != 0 else (o | d).
  * ccv_pixel_unshuffle_rows: x [n,c,H,W] fp32 -> token rows [(n H/r W/r), c r^2] bf16 (torch.nn.PixelUnshuffle order).
@@ -272,8 +276,9 @@ int ccv_cross_norm(const float* x, const float* ref, float* y, int32_t n_slices,
 /* Row softmax fp32 [rows, ldx] -> bf16 [rows, ldy] over L columns: the single-head, 512-wide attention of the first-stage
  * decoder (lvdm/modules/networks/ae_modules.py:66-70) runs as GEMM (QK^T, alpha = C^-1/2) -> this -> GEMM (P V). */
 int ccv_softmax_rows(const float* x, uint16_t* y, int32_t rows, int32_t L, int64_t ldx, int64_t ldy, void* stream);
-/* fp32 -> bf16 (contexts, pose features) with an optional 'b c t h w -> (b t h w) c' transpose. */
-int ccv_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+/* fp32 (x_kind 1) or fp16 (x_kind 2) -> bf16 (contexts, pose features, stream rows that feed a convolution); with an optional
+ * 'b c t h w -> (b t h w) c' transpose (ccv_nchw_to_rows_bf16). */
+int ccv_cast_bf16(const void* x, int32_t x_kind, uint16_t* y, int64_t n, void* stream);
 int ccv_nchw_to_rows_bf16(const float* x, uint16_t* y, int32_t b, int32_t c, int32_t t, int32_t hw, void* stream);
 /* timestep_embedding (lvdm/models/utils_diffusion.py:8-28): t [n] fp32 -> [n, dim] bf16 (cos | sin). */
 int ccv_timestep_embedding(const float* t, uint16_t* out, int32_t n, int32_t dim, void* stream);

@@ -862,3 +862,96 @@ def test_attention_sparse_fp8(ops, hl, H):
     print(f"[parity] fp8 vs bf16 sparse attention, Gaussian operands, {hl}x{hl} latents H={H}: rel_l2={l2:.3e}")
     assert torch.isfinite(out8).all() and l2 < 6e-2
     assert_close(out16, dense_ref(qkv, reg, reg), 1e-2, "bf16 sparse kernel vs fp32 (sanity of the reference construction)")
+
+
+# ------------------------------------------------------------------------------------------
+# fp16 residual stream (round 3): every kernel family's epilogue, the norms and the layout helpers on fp16 rows
+# ------------------------------------------------------------------------------------------
+def _f16(t):
+    return t.to(torch.float16)
+
+
+@pytest.mark.parametrize("M,N,K,taps", [(32768, 320, 320, 1),      # A-stationary kernel (K = 320, one 128-row workgroup per CU)
+                                        (4096, 1280, 640, 1),      # family tile, two-stage loop
+                                        (512, 1280, 1280, 1),      # family tile, 3-stage ring (M <= 1024)
+                                        (512, 1280, 5120, 1),      # split-K: the reduce kernel owns the epilogue
+                                        (300, 320, 320, 1),        # ragged rows
+                                        (2048, 640, 640, 3)])      # stacked segments on a ring / family tile
+def test_gemm_fp16_stream_epilogues(ops, M, N, K, taps):
+    """out = A W^T + bias + residual with the residual and the output in fp16 (fp32 arithmetic): against torch fp32, tolerance =
+    fp16's 2^-11 relative rounding of the stored sum + the accumulation order; in place (C aliases the residual) as the UNet runs it."""
+    a = rnd(taps * M, K, seed=21)
+    w = rnd(N, taps * K, seed=22, scale=0.05)
+    bias = rnd(N, seed=23, dtype=torch.float32)
+    res = _f16(rnd(M, N, seed=24, dtype=torch.float32))
+    kw = dict(k=K, taps=taps, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=M) if taps > 1 else {}
+    ref = sum(a[t * M:(t + 1) * M].float() @ w[:, t * K:(t + 1) * K].float().t() for t in range(taps)) + bias + res.float()
+    out = ops.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float16, **kw)
+    assert out.dtype == torch.float16
+    assert_close(out, ref, 1.5e-3, f"fp16 stream {M}x{N}x{K} taps {taps}")
+    stream = res.clone()
+    ops.gemm(a, w, bias=bias, residual=stream, out_dtype=torch.float16, out=stream, **kw)
+    assert torch.equal(stream, out), "in-place update differs from the out-of-place one"
+    # fp16 residual into a bf16 output (last feed-forward of a transformer) and a fresh fp16 output without residual (proj_in)
+    outb = ops.gemm(a, w, bias=bias, residual=res, **kw)
+    assert outb.dtype == torch.bfloat16
+    assert_close(outb, ref, 1e-2, "fp16 residual, bf16 out")
+    outn = ops.gemm(a, w, bias=bias, out_dtype=torch.float16, **kw)
+    assert_close(outn, ref - res.float(), 1.5e-3, "fp16 out, no residual")
+
+
+def test_gemm_fp16_stream_convs(ops):
+    """conv3x3 (+ fp16 residual) and the temporal convolution writing the fp16 stream."""
+    from camc2v_amd.pack import pack_conv3x3, pack_tconv3
+    n, cin, cout, hs = 16, 320, 320, 16
+    x = rnd(n, cin, hs, hs, seed=25, dtype=torch.float32).to(torch.bfloat16).float()
+    wt = rnd(cout, cin, 3, 3, seed=26, scale=0.03, dtype=torch.float32).to(torch.bfloat16).float()
+    bias = rnd(cout, seed=27, dtype=torch.float32)
+    res = _f16(rnd(n * hs * hs, cout, seed=28, dtype=torch.float32))
+    ref = F.conv2d(x, wt, bias, padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
+    rows = x.permute(0, 2, 3, 1).reshape(-1, cin).to(torch.bfloat16).contiguous()
+    out = ops.gemm(rows, pack_conv3x3(wt), k=cin, taps=9, bias=bias, residual=res, gather=ops.GATHER_CONV3X3, conv=(hs, hs, hs, hs, 1, 0),
+                   out_dtype=torch.float16)
+    assert_close(out, ref, 1.5e-3, "conv3x3 fp16 stream")
+    b, c, t, hw = 2, 320, 16, 64
+    xt = rnd(b, c, t, hw, 1, seed=29, dtype=torch.float32).to(torch.bfloat16).float()
+    w3 = rnd(c, c, 3, 1, 1, seed=30, scale=0.03, dtype=torch.float32).to(torch.bfloat16).float()
+    rest = _f16(rnd(b * t * hw, c, seed=31, dtype=torch.float32))
+    reft = F.conv3d(xt, w3, None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(-1, c) + rest.float()
+    rowst = xt[..., 0].permute(0, 2, 3, 1).reshape(-1, c).to(torch.bfloat16).contiguous()
+    outt = ops.gemm(rowst, pack_tconv3(w3), k=c, taps=3, gather=ops.GATHER_TCONV3, tconv=(t, hw), residual=rest, out_dtype=torch.float16)
+    assert_close(outt, reft, 1.5e-3, "tconv3 fp16 stream")
+
+
+@pytest.mark.parametrize("rows,C,instances", [(32768, 320, 32), (32768, 320, 2), (2048, 1280, 32), (512, 1280, 2), (8192, 640, 32)])
+def test_groupnorm_fp16_rows(ops, rows, C, instances):
+    """GroupNorm(32)+SiLU on fp16 rows (chunked two-launch path and the single-launch one) against torch fp32 on the same values."""
+    x = _f16(rnd(rows, C, seed=32, dtype=torch.float32) * 1.7 + 0.3)
+    gamma, beta = rnd(C, seed=33, dtype=torch.float32), rnd(C, seed=34, dtype=torch.float32)
+    y = ops.groupnorm(x, gamma, beta, instances=instances, eps=1e-5, silu=True)
+    xr = x.float().reshape(instances, rows // instances, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xr, 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, C)
+    assert_close(y, ref, 1e-2, "groupnorm fp16 rows")
+    # the fp32 path on the same values (the single-launch / chunked choice depends on the element size, i.e. the summation order may differ)
+    assert_close(y, ops.groupnorm(x.float(), gamma, beta, instances=instances, eps=1e-5, silu=True), 8e-3, "fp16 rows vs the same values as fp32 rows")
+
+
+@pytest.mark.parametrize("rows,C", [(32768, 320), (8192, 640), (2048, 1280), (100, 320)])
+def test_layernorm_fp16_rows(ops, rows, C):
+    x = _f16(rnd(rows, C, seed=35, dtype=torch.float32) * 2.0 - 0.5)
+    gamma, beta = rnd(C, seed=36, dtype=torch.float32), rnd(C, seed=37, dtype=torch.float32)
+    add = rnd(rows // 2 if rows % 2 == 0 else rows, C, seed=38)
+    y, y2 = ops.layernorm(x, gamma, beta, addend=add)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    assert_close(y, ref, 1e-2, "layernorm fp16 rows")
+    assert_close(y2, ref + add.float().repeat(rows // add.shape[0], 1), 1e-2, "layernorm fp16 rows + addend")
+    assert torch.equal(y, ops.layernorm(x.float(), gamma, beta))
+
+
+def test_concat_and_cast_fp16_rows(ops):
+    a, b = _f16(rnd(4096, 640, seed=39, dtype=torch.float32)), _f16(rnd(4096, 320, seed=40, dtype=torch.float32))
+    out, out16 = ops.concat_rows(a, b, with_bf16=True)
+    ref = torch.cat([a, b], 1)
+    assert out.dtype == torch.float16 and torch.equal(out, ref)
+    assert torch.equal(out16, ref.float().to(torch.bfloat16))
+    assert torch.equal(ops.cast_bf16(a), a.float().to(torch.bfloat16))
