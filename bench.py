@@ -293,11 +293,38 @@ def dominant_kernel(model, device, inputs, reps=20):
     fl_exec = 0.5 * (flops[0] * visited[0] + flops[1] * visited[1])
     tf = fl / us / 1e6
     return dict(kernel="attn_sparse_kernel", us_per_launch=us, us_per_launch_isolated=us_isolated, launches_timed_in_model=len(timed),
-                flops_per_launch=fl, achieved=tf, frac=tf / PEAK_BF16_TFLOPS,
+                flops_per_launch=fl, achieved_dense=tf, frac_dense=tf / PEAK_BF16_TFLOPS,
                 executed_fraction=fl_exec / fl, effective_tflops=fl_exec / us / 1e6,
                 problem="masked epipolar attention, b=2 (cond+uncond), L=16384 H=5 (x5) and L=4096 H=10 (x5) per CFG step, 4 register "
                         "tokens, benchmark masks; dense FLOP convention 4 Lq Lk 64 H b",
                 visited_block_fraction={"32x32": visited[0], "16x16": visited[1]})
+
+
+def gemm_family(model, device, inputs, steps=2):
+    """The GEMM family (ccv_gemm: every linear layer, 3x3 / temporal convolution and stacked projection; ~64 % of the kernel time of
+    a clip) timed live: HIP events on the launch stream around every ccv_gemm call (split-K reduce launches included) of eager CFG
+    steps of the benchmark clip (`ops.GEMM_PROBE`; one warm-up step, `steps` timed).  FLOPs = sum of 2 M N K taps of the calls,
+    i.e. executed work (context K/V projections are cached per clip and do not appear)."""
+    from camc2v_amd import ops
+    cond, uncond, fs, x_T, _ = inputs
+    t = torch.full((x_T.shape[0],), 439, dtype=torch.long, device=device)
+    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True))
+    with torch.no_grad():
+        model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)      # warm-up (caches, allocator)
+        torch.cuda.synchronize()
+        ops.GEMM_PROBE = probe = []
+        try:
+            for _ in range(steps):
+                model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.GEMM_PROBE = None
+    ms = sum(a.elapsed_time(b) for a, b, _ in probe) / steps
+    tf = sum(f for _, _, f in probe) / steps / 1e12
+    return dict(calls_per_cfg_step=len(probe) // steps, ms_per_cfg_step=ms, executed_tflop_per_cfg_step=tf, achieved=tf / ms * 1e3,
+                frac=tf / ms * 1e3 / PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                note="every ccv_gemm call of one eager CFG step (b = 2), HIP events on the launch stream; the events' own cost "
+                     "(~1 us per call) is inside the figure")
 
 
 def two_clips_per_forward(model, device, use_graph, rank=0, calls=2):
@@ -339,7 +366,7 @@ def skipped_flops(inputs):
     return epi_clip, kv_ref - kv_here
 
 
-def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None, lanes=1, sharded=False):
+def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None, lanes=1, sharded=False, gemm=None):
     from camc2v_amd import configs
     clips = steps if sharded else steps * world          # frame-sharded: the ranks sample each clip TOGETHER
     tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
@@ -356,9 +383,11 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
                               "fraction_of_dense": (epi + kv) / tf_per_clip})
     roof = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None}
     if dom is not None:
-        roof.update(achieved=dom["achieved"], frac=dom["frac"], kernel=dom["kernel"], us_per_launch=dom["us_per_launch"],
-                    flops_per_launch=dom["flops_per_launch"], executed_fraction=dom["executed_fraction"],
-                    effective_tflops=dom["effective_tflops"], problem=dom["problem"],
+        # achieved / frac: what the hardware does -- FLOPs of the 32-key blocks the kernel actually multiplies / time; the reference's
+        # dense count (mask ignored) beside it as achieved_dense / frac_dense
+        roof.update(achieved=dom["effective_tflops"], frac=dom["effective_tflops"] / PEAK_BF16_TFLOPS,
+                    achieved_dense=dom["achieved_dense"], frac_dense=dom["frac_dense"], kernel=dom["kernel"], us_per_launch=dom["us_per_launch"],
+                    flops_per_launch=dom["flops_per_launch"], executed_fraction=dom["executed_fraction"], problem=dom["problem"],
                     visited_block_fraction=dom["visited_block_fraction"],
                     us_per_launch_isolated=dom.get("us_per_launch_isolated"), launches_timed_in_model=dom.get("launches_timed_in_model"))
     if os.path.exists(TRAFFIC_FILE):     # HBM-side bytes per launch of the dominant kernel from this round's PMC passes
@@ -369,6 +398,8 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
             whole["traffic_bytes_per_clip"] = tr.get("bytes_per_clip")
         except (OSError, ValueError):
             pass
+    if gemm is not None:
+        roof["gemm_family"] = gemm
     roof["whole_path"] = whole
     line = {
         "metric": "denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
@@ -522,8 +553,9 @@ def main(argv=None, hooks=None):
         extras = on_gpu and hooks.get("extras", True) and not args.clips_only
         dom = dominant_kernel(model, device, sets[0]) if extras else None
         skipped = skipped_flops(sets[0]) if extras else None
+        gemm = gemm_family(model, device, sets[0]) if extras and not sharded else None
         line = result_line(elapsed, args.steps, args.warmup, world, use_graph, dev_ms, dom, skipped, ranks_seen, lanes,
-                           ("cfg-split2" if args.cfg_split else sharded) if sharded else False)
+                           ("cfg-split2" if args.cfg_split else sharded) if sharded else False, gemm)
         if first_ms:
             line["config"]["first_clip_ms"] = first_ms["v"]    # includes packing, graph capture (a new signature) and caches
         if world == 1 and extras and lanes > 1:      # the same clips one at a time (one stream), for comparison

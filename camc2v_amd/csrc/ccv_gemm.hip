@@ -133,14 +133,16 @@ __device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, c
 }
 
 
-// GroupNorm(32) statistics of the tile just computed (p.gn_partial; bf16 outputs that feed a GroupNorm): sums and sums of squares
-// of every group's channels over this tile's rows, of the values AS STORED (epilogue applied, rounded to bf16), written to slot
-// (row tile inside the instance) * (column tiles) + (column tile) of the instance the tile's rows belong to -- the layout
-// gn_apply's prologue reduces (ccv_norm.hip).  Work per lane: its 4 columns of a row are two channel PAIRS, and a pair never
-// straddles a group (channels per group are even); pair sums accumulate over the wave's row fragments, fold over the 16 row lanes
-// with shuffles, land in LDS (the operand stages are free by now) and 64 threads -- one per (group, moment) -- add up their group's
-// entries in a fixed order: no atomics, bitwise reproducible.  Tile geometry shared by gemm_dma_kernel and gemm_ring_kernel:
-// 2 x 2 waves, wave tile 16 MT x 16 NT, lane = row (lane & 15) x column quad (lane >> 4) of a 16 x 16 fragment.
+// Epilogue of the statistics-emitting kernel instances (p.gn_partial; the output feeds a GroupNorm(32)): the normal epilogue
+// (alpha, bias, bias2, residual, store as bf16 / fp16 / fp32) AND the sums and sums of squares of every group's channels over this
+// tile's rows, of the values AS STORED (rounded to the output type), written to slot (row tile inside the instance) * (column
+// tiles) + (column tile) of the instance the tile's rows belong to -- the layout gn_apply's prologue reduces (ccv_norm.hip).
+// Work per lane: its 4 columns of a row are two channel PAIRS, and a pair never straddles a group (channels per group are even);
+// pair sums accumulate over the wave's row fragments, fold over the 16 row lanes with DPP steps, land in LDS (the operand stages
+// are free by now) and 64 threads -- one per (group, moment) -- add up their group's entries in a fixed order: no atomics, bitwise
+// reproducible.  Tile geometry shared by gemm_dma_kernel and gemm_ring_kernel: 2 x 2 waves, wave tile 16 MT x 16 NT, lane = row
+// (lane & 15) x column quad (lane >> 4) of a 16 x 16 fragment.  The host admits only problems without activation / GEGLU, with
+// every row inside M and whole tiles inside an instance (ccv_gemm_gn_slots).
 __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row (= the 16 rows of a fragment), no LDS
     auto step = [](float x, auto ctrl) {
         constexpr int c = decltype(ctrl)::value;
@@ -153,40 +155,45 @@ __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes
     return v;
 }
 
+// store o[0..3] at C[m][n..n+3] in the output type and hand back the values as stored
+__device__ __forceinline__ void store_rounded(const CcvGemm& p, int m, int n, float o[4]) {
+    if (p.out_f32 == 1) {
+        *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (p.out_f32 == 2) {
+        const uint2 pk = make_uint2(pack_f16x2(o[0], o[1]), pack_f16x2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+        const float2 a = unpack_f16x2(pk.x), b = unpack_f16x2(pk.y);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    } else {
+        const uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+        o[0] = __uint_as_float(pk.x << 16); o[1] = __uint_as_float(pk.x & 0xffff0000u);
+        o[2] = __uint_as_float(pk.y << 16); o[3] = __uint_as_float(pk.y & 0xffff0000u);
+    }
+}
+
 template <int MT, int NT>
-__device__ __forceinline__ void tile_gn_stats(const CcvGemm& p, const f32x4 (&acc)[MT][NT], int m0, int n0, int tiles_n, unsigned char* smem) {
+__device__ __forceinline__ void tile_epilogue_gn(const CcvGemm& p, const f32x4 (&acc)[MT][NT], int m0, int n0, int tiles_n, unsigned char* smem) {
     constexpr int BM = 32 * MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, fr = lane & 15, fg = lane >> 4;
-    // the epilogue of these problems is alpha * acc + bias[n] (+ bias2[batch][n], one batch per tile): fetched once per column quad
-    // (the host admits only problems without activation / residual, whole tiles inside a bias2 batch and an instance)
-    float4 bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
-        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.N) {
-            if (p.bias) bv[j] = *reinterpret_cast<const float4*>(p.bias + n);
-            if (p.bias2) {
-                const float4 b2 = *reinterpret_cast<const float4*>(p.bias2 + (long)(m0 / p.rows_per_batch) * p.ldb2 + n);
-                bv[j].x += b2.x; bv[j].y += b2.y; bv[j].z += b2.z; bv[j].w += b2.w;
-            }
-        }
-    }
     float gs[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j) gs[j][0] = gs[j][1] = gs[j][2] = gs[j][3] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {     // (every row is inside M -- host check; columns past N multiply the zero line and get no bias: they add 0)
-            const uint32_t lo = pack_bf16x2(acc[i][j][0] * p.alpha + bv[j].x, acc[i][j][1] * p.alpha + bv[j].y);
-            const uint32_t hi = pack_bf16x2(acc[i][j][2] * p.alpha + bv[j].z, acc[i][j][3] * p.alpha + bv[j].w);
-            const float v0 = bf16_to_f32((uint16_t)(lo & 0xffffu)), v1 = bf16_to_f32((uint16_t)(lo >> 16));
-            const float v2 = bf16_to_f32((uint16_t)(hi & 0xffffu)), v3 = bf16_to_f32((uint16_t)(hi >> 16));
-            gs[j][0] += v0 + v1; gs[j][1] += v0 * v0 + v1 * v1;
-            gs[j][2] += v2 + v3; gs[j][3] += v2 * v2 + v3 * v3;
-        }
-    }
+    static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const int m = m0 + wm * 16 * MT + 16 * i + fr;      // every row is inside M (host check)
+        static_for<0, NT, 1>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
+            if (n < p.N) {                                   // columns past N are not stored and add nothing
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue_math(p, m, n, o);
+                store_rounded(p, m, n, o);
+                gs[j][0] += o[0] + o[1]; gs[j][1] += o[0] * o[0] + o[1] * o[1];
+                gs[j][2] += o[2] + o[3]; gs[j][3] += o[2] * o[2] + o[3] * o[3];
+            }
+        });
+    });
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -215,10 +222,14 @@ __device__ __forceinline__ void tile_gn_stats(const CcvGemm& p, const f32x4 (&ac
     }
 }
 
-// Tiles / gathers that have a statistics-emitting kernel instance (the ones the model's unsplit convolutions at 32x32 and 16x16
-// latents run on: 128x160 and 128x128 / 64x128 family tiles, the 4-deep 128x160 ring; 3x3 and temporal convolutions)
-constexpr bool gn_dma_tile(int mt, int nt, int gather) { return (gather == 1 || gather == 2) && ((mt == 4 && nt == 5) || (mt == 4 && nt == 4) || (mt == 2 && nt == 4)); }
-constexpr bool gn_ring_tile(int mt, int nt, int stages, int gather) { return (gather == 1 || gather == 2) && mt == 4 && nt == 5 && stages == 4; }
+// Tiles / gathers that have a statistics-emitting kernel instance: every family tile for linear layers (proj_out of the
+// transformers), 3x3 and temporal convolutions; the 4-deep 128x160 ring and the 2-deep 128x320 ring (decoder convolutions).
+constexpr bool gn_dma_tile(int mt, int nt, int gather) {
+    return gather >= 0 && gather <= 2 && ((mt == 4 && nt == 5) || (mt == 4 && nt == 4) || (mt == 2 && nt == 4) || (mt == 4 && nt == 2) || (mt == 2 && nt == 2));
+}
+constexpr bool gn_ring_tile(int mt, int nt, int stages, int gather) {
+    return (gather == 1 || gather == 2) && ((mt == 4 && nt == 5 && stages == 4) || (mt == 4 && nt == 10 && stages == 2 && gather == 1));
+}
 
 // Workgroup -> (split, tile).  blockIdx is first remapped so that each XCD (blocks with equal blockIdx % 8 under the observed
 // round-robin dispatch: speed only) owns a contiguous range of work items, then the range is walked
@@ -501,7 +512,7 @@ struct WaitSlab<PER, 0> {
 // counted waits (two slabs in flight, s_waitcnt vmcnt(N) + raw s_barrier, as gemm_ring_kernel but with whole 128-byte rows): for
 // the layers whose time is the sum of their slabs' DMA latencies -- few tiles (<= 1 workgroup per CU anyway) and 10-80 slabs, the
 // 8x8 / 4x4-latent linear layers and temporal convolutions: a two-stage loop pays one exposed L2 / HBM round trip per slab.
-template <int MT, int NT, int GATHER, bool GN = false, int ST = 2>   // GN: instances that end with tile_gn_stats (their own kernels: the tail costs
+template <int MT, int NT, int GATHER, bool GN = false, int ST = 2>   // GN: instances whose epilogue is tile_epilogue_gn (their own kernels: it costs
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 15-50 VGPRs, which the plain instances must not pay)
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions per wave and slab (8 rows each)
@@ -671,6 +682,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
         __syncthreads();   // (the statistics tail reuses the operand stages)
     }
 
+    if constexpr (GN) {      // statistics-emitting instance (launched only with p.gn_partial set and no split-K): its own epilogue
+        tile_epilogue_gn<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+        return;
+    }
     const bool wide = wide_bf16_ok(p);
     static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {   // (a plain loop this large is not unrolled any more)
         constexpr int i = decltype(I)::value;
@@ -730,9 +745,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
             }
         });
     });
-    if constexpr (GN) {
-        if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
-    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -890,6 +902,11 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
         }
     }
 
+    if constexpr (GN) {      // statistics-emitting instance: its own epilogue (the ring has drained: every issued slab was waited for)
+        __syncthreads();
+        tile_epilogue_gn<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+        return;
+    }
     const bool wide = wide_bf16_ok(p);
     static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {   // (a plain loop this large is not unrolled any more)
         constexpr int i = decltype(I)::value;
@@ -945,9 +962,6 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             }
         });
     });
-    if constexpr (GN) {
-        if (p.gn_partial && p.split_k <= 1) tile_gn_stats<MT, NT>(p, acc, m0, n0, tiles_n, smem);
-    }
 }
 
 // split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
@@ -976,6 +990,73 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const CcvGemm p) {
     }
 }
 
+// split-K second pass for outputs that feed a GroupNorm(32) (p.gn_partial): as gemm_splitk_reduce (sum the partial slabs, run the
+// epilogue, store) plus the statistics of the values as stored.  One workgroup owns RB consecutive rows x all N columns: thread
+// (roff, col) sums the column quad `col` of rows r0 + roff, + R, ...; the block folds its pair sums exactly like gn_stats
+// (ccv_norm.hip: fixed order, bitwise reproducible) into slot (r0 - instance start) / RB of the rows' instance.
+__global__ __launch_bounds__(1024) void gemm_splitk_reduce_gn(const CcvGemm p, int RB) {
+    __shared__ __attribute__((aligned(16))) float gsm[1024 * 4];  // [R][cols] x (sum01, sq01, sum23, sq23)
+    const int cols = p.N >> 2;
+    const int col = threadIdx.x % cols, roff = threadIdx.x / cols, R = blockDim.x / cols;
+    const int r0 = blockIdx.x * RB, n = col * 4;
+    const float* ws = static_cast<const float*>(p.ws);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int m = r0 + roff; m < r0 + RB; m += R) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int sp = 0; sp < p.split_k; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + ((long)sp * p.M + m) * p.N + n);
+            o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+        }
+        epilogue_math(p, m, n, o);
+        store_rounded(p, m, n, o);
+        a0 += o[0] + o[1]; a1 += o[0] * o[0] + o[1] * o[1];
+        a2 += o[2] + o[3]; a3 += o[2] * o[2] + o[3] * o[3];
+    }
+    *reinterpret_cast<float4*>(gsm + (roff * cols + col) * 4) = make_float4(a0, a1, a2, a3);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+        const int ppg = (p.N >> 5) >> 1;   // channel pairs per group (channels per group is even)
+        float a = 0.f;
+        for (int i = 0; i < ppg; ++i) {
+            const int pr = g * ppg + i;    // pair -> float4 column pr/2, half pr&1
+            float t = 0.f;
+            for (int ro = 0; ro < R; ++ro) t += gsm[(ro * cols + (pr >> 1)) * 4 + (pr & 1) * 2 + k];
+            a += t;
+        }
+        const int inst = r0 / p.gn_rows, slot = (r0 - inst * p.gn_rows) / RB;
+        p.gn_partial[((long)inst * p.gn_slots + slot) * 64 + threadIdx.x] = a;
+    }
+}
+
+// rows per workgroup of gemm_splitk_reduce_gn: the largest power of two that divides the instance, leaves >= 256 workgroups (or one
+// row each) and no more than GN_MAX_PARTS (512) slots per instance; 0 = this problem cannot take the statistics path
+inline int reduce_gn_rows(int M, int N, int gn_rows) {
+    if (gn_rows <= 0 || M % gn_rows != 0 || N % 64 != 0 || N > 4096) return 0;
+    int rb = 1;
+    while (rb * 2 <= gn_rows && gn_rows % (rb * 2) == 0 && M / (rb * 2) >= 256) rb *= 2;
+    while (gn_rows / rb > 512 && gn_rows % (rb * 2) == 0) rb *= 2;
+    return gn_rows / rb <= 512 ? rb : 0;
+}
+
+inline int launch_reduce(const CcvGemm& p, hipStream_t st) {
+    if (p.gn_partial) {
+        const int rb = reduce_gn_rows(p.M, p.N, p.gn_rows);
+        const int cols = p.N / 4;
+        const int threads = cols * ((256 + cols - 1) / cols);
+        hipLaunchKernelGGL(gemm_splitk_reduce_gn, dim3((unsigned)(p.M / rb)), dim3(threads), 0, st, p, rb);
+        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce + GroupNorm statistics)");
+        return CCV_OK;
+    }
+    const long total = (long)p.M * (p.N / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
+    return CCV_OK;
+}
+
 template <int MT, int NT, bool A_F32, int GATHER, int BKT>
 int launch(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
@@ -989,13 +1070,7 @@ int launch(const CcvGemm& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
     CCV_LAUNCH_CHECK("ccv_gemm");
-    if (p.split_k > 1) {
-        const long total = (long)p.M * (p.N / 4);
-        long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
-        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
-    }
+    if (p.split_k > 1) return launch_reduce(p, st);
     return CCV_OK;
 }
 
@@ -1072,13 +1147,7 @@ int launch_dma_ring(const CcvGemm& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
     CCV_LAUNCH_CHECK("ccv_gemm(dma ring)");
-    if (p.split_k > 1) {
-        const long total = (long)p.M * (p.N / 4);
-        long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
-        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
-    }
+    if (p.split_k > 1) return launch_reduce(p, st);
     return CCV_OK;
 }
 
@@ -1086,13 +1155,13 @@ template <int MT, int NT, int GATHER>
 int launch_dma(const CcvGemm& p, hipStream_t st) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
-    if (!p.gn_partial) {
+    if (!p.gn_partial || p.split_k > 1) {
         const int stages = family_stages(p, BM, BN);
         if (stages >= 3) return launch_dma_ring<MT, NT, GATHER, 3>(p, st);     // (4 stages measured equal to 3: not instantiated)
     }
     const size_t lds = 2 * (BM + BN) * 128;
     if constexpr (gn_dma_tile(MT, NT, GATHER)) {
-        if (p.gn_partial) {   // the statistics-emitting instance
+        if (p.gn_partial && p.split_k <= 1) {   // the statistics-emitting instance (split-K: the reduce kernel emits them)
             auto kern_gn = gemm_dma_kernel<MT, NT, GATHER, true>;
             static bool attr_gn = false;
             if (!attr_gn) {
@@ -1112,13 +1181,7 @@ int launch_dma(const CcvGemm& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
     CCV_LAUNCH_CHECK("ccv_gemm(dma)");
-    if (p.split_k > 1) {
-        const long total = (long)p.M * (p.N / 4);
-        long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
-        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
-    }
+    if (p.split_k > 1) return launch_reduce(p, st);
     return CCV_OK;
 }
 
@@ -1128,7 +1191,7 @@ int launch_ring(const CcvGemm& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN) * (p.split_k > 1 ? p.split_k : 1);
     const size_t lds = (size_t)ST * (BM + BN) * RING_BK * 2;
     if constexpr (gn_ring_tile(MT, NT, ST, GATHER)) {
-        if (p.gn_partial) {   // the statistics-emitting instance
+        if (p.gn_partial && p.split_k <= 1) {   // the statistics-emitting instance (split-K: the reduce kernel emits them)
             auto kern_gn = gemm_ring_kernel<MT, NT, ST, GATHER, true>;
             static bool attr_gn = false;
             if (!attr_gn) {
@@ -1148,13 +1211,7 @@ int launch_ring(const CcvGemm& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, p);
     CCV_LAUNCH_CHECK("ccv_gemm(ring)");
-    if (p.split_k > 1) {
-        const long total = (long)p.M * (p.N / 4);
-        long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p);
-        CCV_LAUNCH_CHECK("ccv_gemm(split-K reduce)");
-    }
+    if (p.split_k > 1) return launch_reduce(p, st);
     return CCV_OK;
 }
 
@@ -1638,10 +1695,7 @@ extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
 
 // Tile the kernel ccv_gemm would run this problem on, when that kernel can emit GroupNorm statistics (gemm_dma_kernel /
 // gemm_ring_kernel, bf16 in and out, one pass over K)
-static bool gn_tile_dims(const CcvGemm& p, int& bm, int& bn) {
-    if (!plan_ok(p) || astat_fits(p) || p.a_f32 || p.out_f32 || p.geglu || p.act != 0 || p.residual != nullptr) return false;
-    const Plan pl = make_plan(p, true);
-    if (pl.split > 1) return false;
+static bool gn_tile_dims(const CcvGemm& p, const Plan& pl, int& bm, int& bn) {
     if (pl.ring >= 0) {
         bm = kRing[pl.ring].bm; bn = kRing[pl.ring].bn;
         return gn_ring_tile(bm / 32, bn / 32, kRing[pl.ring].st, p.gather);
@@ -1658,11 +1712,16 @@ static bool gn_tile_dims(const CcvGemm& p, int& bm, int& bn) {
 
 extern "C" int32_t ccv_gemm_gn_slots(const CcvGemm* pp, int32_t rows_per_instance) {
     if (pp == nullptr || rows_per_instance <= 0) return 0;
-    int bm = 0, bn = 0;
-    if (!gn_tile_dims(*pp, bm, bn)) return 0;
     const CcvGemm& p = *pp;
-    if (p.N % 64 != 0 || p.ldc != p.N || p.M % rows_per_instance != 0 || rows_per_instance % bm != 0) return 0;
-    if (p.bias2 && (p.rows_per_batch <= 0 || p.rows_per_batch % bm != 0)) return 0;     // one bias2 row per tile
+    if (!plan_ok(p) || astat_fits(p) || p.a_f32 || p.geglu || p.act != 0) return 0;
+    if (p.N % 64 != 0 || p.M % rows_per_instance != 0) return 0;
+    const Plan pl = make_plan(p, true);
+    if (pl.split > 1) {      // the reduce kernel emits them: one slot per RB rows of an instance
+        const int rb = reduce_gn_rows(p.M, p.N, rows_per_instance);
+        return rb > 0 ? rows_per_instance / rb : 0;
+    }
+    int bm = 0, bn = 0;
+    if (!gn_tile_dims(p, pl, bm, bn) || rows_per_instance % bm != 0) return 0;
     const long slots = (long)(rows_per_instance / bm) * ((p.N + bn - 1) / bn);
     return slots <= 512 ? (int32_t)slots : 0;   // ccv_norm.hip: GN_MAX_PARTS
 }
@@ -1700,7 +1759,8 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(p.lda >= p.K, CCV_ESHAPE, "ccv_gemm: lda=%d < K=%d", p.lda, p.K);
     CCV_REQUIRE(!p.bias2 || (p.rows_per_batch > 0 && p.ldb2 >= p.N && p.ldb2 % 4 == 0), CCV_EINVAL,
                 "ccv_gemm: bias2 needs rows_per_batch > 0 and ldb2 >= N (multiple of 4)");
-    CCV_REQUIRE(!p.gn_partial || (p.gn_rows > 0 && p.gn_slots > 0 && p.split_k <= 1 && p.gn_slots == ccv_gemm_gn_slots(&p, p.gn_rows)), CCV_EINVAL,
+    CCV_REQUIRE(!p.gn_partial || (p.gn_rows > 0 && p.gn_slots > 0 && p.gn_slots == ccv_gemm_gn_slots(&p, p.gn_rows) &&
+                                  (ccv_gemm_ws_bytes(&p) == 0 || p.split_k > 1)), CCV_EINVAL,
                 "ccv_gemm: gn_partial needs gn_rows and gn_slots = ccv_gemm_gn_slots() > 0 for this problem (got rows %d, slots %d)", p.gn_rows, p.gn_slots);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (plan_ok(p) && astat_fits(p)) return dispatch_astat(p, st);

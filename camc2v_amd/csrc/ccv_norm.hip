@@ -419,6 +419,13 @@ extern "C" int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const fl
     return CCV_OK;
 }
 
+// 1 when ccv_groupnorm would run this problem as ONE launch (gn_small): statistics from a producer's epilogue then save nothing
+extern "C" int32_t ccv_groupnorm_single_launch(int32_t instances, int32_t rows_per_instance, int32_t C, int32_t x_kind) {
+    if (instances <= 0 || rows_per_instance <= 0 || C <= 0 || C % 64 != 0) return 0;
+    static const bool small_on = [] { const char* e = getenv("CCV_GN_SMALL"); return !(e && e[0] == '0'); }();
+    return (small_on && gn_small_gpb(instances, rows_per_instance, C, x_kind == CCV_F32) > 0) ? 1 : 0;
+}
+
 // The two halves of ccv_groupnorm as separate calls, for statistics that span more rows than this process holds (a clip whose
 // frames are sharded over GPUs: the caller sums the per-chunk partials, all-reduces them and hands the totals back).
 extern "C" int32_t ccv_groupnorm_chunks(int32_t instances, int32_t rows_per_instance, int32_t C) {

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
     "ccv_groupnorm_chunks": (i32, [i32, i32, i32]),
+    "ccv_groupnorm_single_launch": (i32, [i32, i32, i32, i32]),
     "ccv_groupnorm_stats": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "ccv_groupnorm_apply": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, f32, vp]),
     "ccv_groupnorm": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]),

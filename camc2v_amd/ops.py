@@ -151,7 +151,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     p.rows_per_batch = rows_per_batch
     p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), {BF16: 0, F32: 1, F16: 2}[out_dtype], alpha
     stats = None
-    if gn_rows:
+    if gn_rows and M % gn_rows == 0 and not lib().ccv_groupnorm_single_launch(M // gn_rows, gn_rows, n_cols, _KIND[out_dtype]):
         slots = lib().ccv_gemm_gn_slots(C.byref(p), gn_rows)
         if slots > 0:
             part = torch.empty((M // gn_rows, slots, 64), dtype=F32, device=a.device)
@@ -168,13 +168,21 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         tile, split = C.c_int32(0), C.c_int32(0)
         check(lib().ccv_gemm_plan(C.byref(p), C.byref(tile), C.byref(split)), "ccv_gemm_plan")
         LAST_GEMM_PLAN = (tile.value, split.value)
+    probe = GEMM_PROBE
+    if probe is not None:      # measurement aid (bench.py): HIP events on the launch stream around this GEMM's launch(es)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().ccv_gemm(C.byref(p), _stream()), "ccv_gemm")
+    if probe is not None:
+        e1.record()
+        probe.append((e0, e1, 2.0 * M * N * K * taps))
     return (out, stats) if gn_rows else out
 
 
 # tests / tuning tools: when TRACK_GEMM_PLAN is set, LAST_GEMM_PLAN = (ring tile index or -1, split-K) of the last call
 TRACK_GEMM_PLAN = False
 LAST_GEMM_PLAN = None
+GEMM_PROBE = None     # a list: gemm() appends (start event, end event, 2 M N K taps) per call (eager mode only; bench.py's gemm_family)
 
 
 # ---------------------------------------------------------------------------------------
@@ -328,8 +336,14 @@ def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wa
 # ---------------------------------------------------------------------------------------
 def groupnorm(x, gamma, beta, *, instances, eps, silu, stats=None):
     """x [rows, C] fp32|fp16|bf16 -> bf16; statistics per (instance, group of C/32 channels).  stats: what ``gemm(..., gn_rows=)``
-    returned for the GEMM that produced x (the statistics pass is skipped), or None."""
+    returned for the GEMM that produced x (the statistics pass is skipped), or None; a tensor tagged by ``tag_stats`` carries them."""
     _dev(x, gamma, beta)
+    if stats is None:
+        stats = getattr(x, "_ccv_gn", None)
+        if stats is not None and (stats[1] * instances != x.shape[0] or stats[2] != x._version):
+            stats = None      # produced for another instance size, or the tensor was written since
+        elif stats is not None:
+            stats = stats[:2]
     rows, Cc = _rows(x)
     if rows % instances:
         raise CcvError("groupnorm: rows not divisible by instances")
@@ -346,6 +360,14 @@ def groupnorm(x, gamma, beta, *, instances, eps, silu, stats=None):
     check(lib().ccv_groupnorm(_ptr(x), xk, _ptr(y), _ptr(gamma), _ptr(beta), instances,
                               rows // instances, Cc, eps, int(silu), _ptr(ws), _stream()), "ccv_groupnorm")
     return y
+
+
+def tag_stats(out, stats):
+    """Let ``out`` carry the GroupNorm statistics its producing GEMM emitted (``gemm(..., gn_rows=)`` -> (out, stats)): the next
+    ``groupnorm(out, ...)`` with matching instances skips its statistics pass.  The tag dies with any in-place write to ``out``."""
+    if stats is not None:
+        out._ccv_gn = (stats[0], stats[1], out._version)
+    return out
 
 
 def groupnorm_sharded(x, gamma, beta, *, instances, eps, silu, reduce_sums, total_rows_per_instance):

@@ -57,15 +57,28 @@ def _dev_f32(p):
 _PACK_LOCK = threading.RLock()
 
 
-# GroupNorm statistics from the producing convolution's epilogue (ops.gemm(gn_rows=) -> ops.groupnorm(stats=)): the second norm of a
-# ResBlock (one instance per frame) and the norms inside a temporal convolution block (one instance per clip: 256-320 tiles, i.e.
-# statistics slots, per instance at 32x32 / 16x16 latents).  Built, parity-tested and measured on MI355X (tools/gn_epilogue_probe.py,
-# profiles/r02_gn_epilogue.txt): every conv + norm pair gets 2-10 us shorter in isolation, 6 / 36 launches per step disappear, but with
-# two clips in flight the frame rate does not move (28.14 off, 27.98 frame-wise only, 28.04 both; one clip at a time +0.2 %) -- most
-# ResBlock convolutions of the 16x16 .. 4x4 levels run split-K, whose reduce kernel owns the epilogue.  Off unless CCV_GN_EPILOGUE=1
-# (frame-wise) / CCV_GN_EPILOGUE_CLIP=1 (clip-wide).
-FRAME_NORM_STATS_FROM_EPILOGUE = os.environ.get("CCV_GN_EPILOGUE", "0") == "1"
-CLIP_NORM_STATS_FROM_EPILOGUE = os.environ.get("CCV_GN_EPILOGUE_CLIP", "0") == "1"
+# GroupNorm statistics from the producer's epilogue: every GEMM whose output feeds a GroupNorm(32) that would otherwise take the
+# two-launch path is asked for them (ops.gemm(gn_rows=): conv / temporal-conv tiles, transformer output projections, the split-K
+# reduce pass; residual added, values as stored) and its output carries them to ``ops.groupnorm`` (ops.tag_stats), which then runs
+# its normalise half only.  Producers whose kernel cannot emit them (the A-stationary kernel of the K = 320 projections, concat)
+# leave the norm to compute its own.  CCV_GN_EPILOGUE=0 (A/B aid) switches the hand-over off.
+GN_STATS_FROM_EPILOGUE = os.environ.get("CCV_GN_EPILOGUE", "1") != "0"
+
+
+def _gn_rows(kind, g):
+    """Rows per GroupNorm instance of the layer that consumes an output: 'frame' (ResBlock / SpatialTransformer norms), 'clip'
+    (TemporalConvBlock / TemporalTransformer norms), None (no norm follows, or frames are sharded over ranks)."""
+    if not GN_STATS_FROM_EPILOGUE or kind is None or parallel.current() is not None:
+        return None
+    return g.h * g.w if kind == "frame" else g.t * g.h * g.w
+
+
+def _gemm_gn(gn_rows, *a, **kw):
+    """ops.gemm whose output carries its GroupNorm statistics when `gn_rows` is given and the kernel can emit them."""
+    if gn_rows is None:
+        return ops.gemm(*a, **kw)
+    out, st = ops.gemm(*a, gn_rows=gn_rows, **kw)
+    return ops.tag_stats(out, st)
 
 
 def _clip_groupnorm(x, gamma, beta, g, eps, silu):
@@ -495,14 +508,15 @@ class SpatialTransformer(nn.Module, _Prepared):
                     w_in=pack.pack_linear(self.proj_in.weight), b_in=_dev_f32(self.proj_in.bias),
                     w_out=pack.pack_linear(self.proj_out.weight), b_out=_dev_f32(self.proj_out.bias))
 
-    def forward_rows(self, x, g, ctx_groups_per_block):
+    def forward_rows(self, x, g, ctx_groups_per_block, next_norm=None):
+        """next_norm: 'frame' / 'clip' / None -- the GroupNorm that consumes the output (its statistics come out of proj_out's epilogue)."""
         pk = self._pk()
         n = ops.groupnorm(x, pk["gn_g"], pk["gn_b"], instances=g.b * g.t, eps=self.norm.eps, silu=False)
         s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_dtype=x.dtype)
         last = len(self.transformer_blocks) - 1
         for i, (blk, groups) in enumerate(zip(self.transformer_blocks, ctx_groups_per_block)):
             s = blk.run_spatial(s, g, groups, final=(i == last))
-        return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_dtype=x.dtype)
+        return _gemm_gn(_gn_rows(next_norm, g), s, pk["w_out"], bias=pk["b_out"], residual=x, out_dtype=x.dtype)
 
 
 class TemporalTransformer(nn.Module, _Prepared):
@@ -532,14 +546,14 @@ class TemporalTransformer(nn.Module, _Prepared):
 
     _pack = SpatialTransformer._pack
 
-    def forward_rows(self, x, g, cam):
+    def forward_rows(self, x, g, cam, next_norm=None):
         pk = self._pk()
         n = _clip_groupnorm(x, pk["gn_g"], pk["gn_b"], g, self.norm.eps, False)
         s = ops.gemm(n, pk["w_in"], bias=pk["b_in"], out_dtype=x.dtype)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             s = blk.run_temporal(s, g, cam, final=(i == last))
-        return ops.gemm(s, pk["w_out"], bias=pk["b_out"], residual=x, out_dtype=x.dtype)
+        return _gemm_gn(_gn_rows(next_norm, g), s, pk["w_out"], bias=pk["b_out"], residual=x, out_dtype=x.dtype)
 
 
 # =============================================================================================
@@ -564,14 +578,15 @@ class Downsample(nn.Module, _Prepared):
     def _pack(self):
         return dict(w=pack.pack_conv3x3(self.op.weight), b=_dev_f32(self.op.bias))
 
-    def forward_rows(self, x, g):
+    def forward_rows(self, x, g, next_norm=None):
         pk = self._pk()
         oh, ow = (g.h + 1) // 2, (g.w + 1) // 2
         sd = x.dtype
         x = ops.cast_bf16(x)   # bf16 operand: the conv then runs on the LDS-DMA kernel (a stream-typed A needs register staging)
-        y = ops.gemm(x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_dtype=sd,
+        go = Geom(g.b, g.t, oh, ow)
+        y = _gemm_gn(_gn_rows(next_norm, go), x, pk["w"], k=self.channels, taps=9, m=g.b * g.t * oh * ow, bias=pk["b"], out_dtype=sd,
                      gather=ops.GATHER_CONV3X3, conv=(oh, ow, g.h, g.w, 2, 0))
-        return y, Geom(g.b, g.t, oh, ow)
+        return y, go
 
 
 class Upsample(nn.Module, _Prepared):
@@ -585,7 +600,7 @@ class Upsample(nn.Module, _Prepared):
     def _pack(self):
         return dict(w=pack.pack_conv3x3(self.conv.weight), b=_dev_f32(self.conv.bias))
 
-    def forward_rows(self, x, g):
+    def forward_rows(self, x, g, next_norm=None):
         pk = self._pk()
         oh, ow = 2 * g.h, 2 * g.w   # nearest 2x is folded into the conv's gather
         sd = x.dtype
@@ -618,15 +633,14 @@ class TemporalConvBlock(nn.Module, _Prepared):
             pk[f"w{i}"], pk[f"cb{i}"] = pack.pack_tconv3(seq[-1].weight), _dev_f32(seq[-1].bias)
         return pk
 
-    def forward_rows(self, x, g):
+    def forward_rows(self, x, g, next_norm=None):
         pk = self._pk()
         C = self.in_channels
         h = x
         fc = parallel.current()
-        st = None      # GroupNorm statistics of h from the epilogue of the convolution that produced it (whole clip = one instance)
         for i in range(4):
-            if fc is None:
-                z = ops.groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], instances=g.b, eps=1e-5, silu=True, stats=st)
+            if fc is None:    # (h carries the statistics its producing convolution emitted: whole clip = one instance)
+                z = ops.groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], instances=g.b, eps=1e-5, silu=True)
             else:
                 z = _clip_groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], g, 1e-5, True)
             last = i == 3
@@ -640,13 +654,11 @@ class TemporalConvBlock(nn.Module, _Prepared):
                     h = (h + x.float()).to(x.dtype)
                 continue
             if last:
-                h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w), residual=x,
-                             out_dtype=x.dtype)
-            elif CLIP_NORM_STATS_FROM_EPILOGUE:
-                h, st = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w),
-                                 gn_rows=g.t * g.h * g.w)
+                h = _gemm_gn(_gn_rows(next_norm, g), z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3,
+                             tconv=(g.t, g.h * g.w), residual=x, out_dtype=x.dtype)
             else:
-                h = ops.gemm(z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t, g.h * g.w))
+                h = _gemm_gn(_gn_rows("clip", g), z, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3,
+                             tconv=(g.t, g.h * g.w))
         return h
 
 
@@ -693,7 +705,7 @@ class ResBlock(TimestepBlock, _Prepared):
             pk["skip_taps"] = 9 if sc.kernel_size[0] == 3 else 1
         return pk
 
-    def forward_rows(self, x, emb_all, g, x_bf16=None):
+    def forward_rows(self, x, emb_all, g, x_bf16=None, next_norm=None):
         """x [(b t h w), Cin] in the stream dtype; emb_all fp32 [b, sum Cout] (all ResBlock emb projections in one GEMM);
         x_bf16: optional bf16 rounding of x (what the skip convolution's operand load would produce anyway)."""
         pk = self._pk()
@@ -702,12 +714,10 @@ class ResBlock(TimestepBlock, _Prepared):
         off, width = self.emb_slice
         assert width == cout
         h = ops.groupnorm(x, pk["g1"], pk["b1"], instances=g.b * g.t, eps=1e-5, silu=True)
-        # (optionally) the second norm's statistics come out of the first convolution's epilogue where its kernel can produce them
-        h = ops.gemm(h, pk["w1"], k=cin, taps=9, bias=pk["cb1"], bias2=emb_all[:, off:], ldb2=emb_all.stride(0),
-                     rows_per_batch=g.t * g.h * g.w, gather=ops.GATHER_CONV3X3, conv=conv,
-                     gn_rows=g.h * g.w if FRAME_NORM_STATS_FROM_EPILOGUE else None)
-        h, st = h if FRAME_NORM_STATS_FROM_EPILOGUE else (h, None)
-        h = ops.groupnorm(h, pk["g2"], pk["b2"], instances=g.b * g.t, eps=1e-5, silu=True, stats=st)
+        # the second norm's statistics come out of the first convolution's epilogue (or its split-K reduce pass)
+        h = _gemm_gn(_gn_rows("frame", g), h, pk["w1"], k=cin, taps=9, bias=pk["cb1"], bias2=emb_all[:, off:], ldb2=emb_all.stride(0),
+                     rows_per_batch=g.t * g.h * g.w, gather=ops.GATHER_CONV3X3, conv=conv)
+        h = ops.groupnorm(h, pk["g2"], pk["b2"], instances=g.b * g.t, eps=1e-5, silu=True)
         skip = x
         if "ws" in pk:
             # operand of the skip convolution: the bf16 rounding the caller already made, else the fp32 stream itself (register-staged
@@ -717,10 +727,10 @@ class ResBlock(TimestepBlock, _Prepared):
                 skip = ops.gemm(xs, pk["ws"], k=cin, taps=9, bias=pk["bs"], out_dtype=x.dtype, gather=ops.GATHER_CONV3X3, conv=conv)
             else:
                 skip = ops.gemm(xs, pk["ws"], bias=pk["bs"], out_dtype=x.dtype)
-        out = ops.gemm(h, pk["w2"], k=cout, taps=9, bias=pk["cb2"], residual=skip, out_dtype=skip.dtype,
-                       gather=ops.GATHER_CONV3X3, conv=conv)
+        out = _gemm_gn(_gn_rows("clip" if self.use_temporal_conv else next_norm, g), h, pk["w2"], k=cout, taps=9, bias=pk["cb2"],
+                       residual=skip, out_dtype=skip.dtype, gather=ops.GATHER_CONV3X3, conv=conv)
         if self.use_temporal_conv:
-            out = self.temopral_conv.forward_rows(out, g)
+            out = self.temopral_conv.forward_rows(out, g, next_norm)
         return out
 
 
@@ -877,6 +887,7 @@ class UNetModel(nn.Module, _Prepared):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(),
                                  _zero(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
+        self.__dict__["out_norm_marker"] = object()     # stands for `self.out` (GroupNorm over a frame) in the forward's lookahead
         self._inputs = _InputCache()
         self._register_load_state_dict_pre_hook(lambda *a, **k: self.invalidate_all())
 
@@ -1130,17 +1141,25 @@ class UNetModel(nn.Module, _Prepared):
             mask = cam["masks"].get(origin_h // hh) if cam["masks"] else None
             return dict(rows=rows, mask=mask, add_type=cam["add_type"])
 
-        def run(block, h, g, level, h16=None):
-            for layer in block:
+        def norm_of(layer):     # the GroupNorm a layer starts with: over a frame, over a clip, or none
+            if isinstance(layer, (ResBlock, SpatialTransformer)) or layer is self.out_norm_marker:
+                return "frame"
+            return "clip" if isinstance(layer, TemporalTransformer) else None
+
+        def run(block, h, g, level, h16=None, after=None):
+            """after: the layer that consumes the block's output directly (None: a concat or nothing)."""
+            layers = list(block)
+            for idx, layer in enumerate(layers):
+                nn_ = norm_of(layers[idx + 1] if idx + 1 < len(layers) else after)
                 if isinstance(layer, ResBlock):
-                    h = layer.forward_rows(h, emb_state[0], g, h16)
+                    h = layer.forward_rows(h, emb_state[0], g, h16, nn_)
                     h16 = None
                 elif isinstance(layer, SpatialTransformer):
-                    h = layer.forward_rows(h, g, [next(ctx_iter) for _ in layer.transformer_blocks])
+                    h = layer.forward_rows(h, g, [next(ctx_iter) for _ in layer.transformer_blocks], nn_)
                 elif isinstance(layer, TemporalTransformer):
-                    h = layer.forward_rows(h, g, cam_for(level, g.h))
+                    h = layer.forward_rows(h, g, cam_for(level, g.h), nn_)
                 elif isinstance(layer, (Downsample, Upsample)):
-                    h, g = layer.forward_rows(h, g)
+                    h, g = layer.forward_rows(h, g, nn_)
                 else:
                     raise CcvError(f"unexpected layer {type(layer).__name__} in a UNet block")
             return h, g
@@ -1150,7 +1169,8 @@ class UNetModel(nn.Module, _Prepared):
         h = ops.gemm(rows, pk["w_in"], k=pk["cin_pad"], taps=9, bias=pk["b_in"], out_dtype=STREAM,
                      gather=ops.GATHER_CONV3X3, conv=(H, W, H, W, 1, 0))
         if self.addition_attention:
-            h = self.init_attn[0].forward_rows(h, g, None)  # never camera conditioned (modified_forwards.py:80-81)
+            # never camera conditioned (modified_forwards.py:80-81); its output feeds the first ResBlock's norm
+            h = self.init_attn[0].forward_rows(h, g, None, None if shared else "frame")
         def widen(rows_b0):   # [b0 rows] -> [cond rows | uncond rows]
             return torch.cat([rows_b0, rows_b0], 0)
 
@@ -1170,7 +1190,8 @@ class UNetModel(nn.Module, _Prepared):
                     hs = [(widen(hh), Geom(b, gg.t, gg.h, gg.w)) for hh, gg in hs]
                     emb_state[0] = widen(emb_all)
                     layers = layers[n_free:]
-            h, g = run(layers, h, g, int(math.log2(self.input_ds[i])))
+            nxt_block = self.input_blocks[i + 1] if i + 1 < len(self.input_blocks) else self.middle_block
+            h, g = run(layers, h, g, int(math.log2(self.input_ds[i])), after=None if (shared and g.b == b0) else nxt_block[0])
             hs.append((h, g))
         if shared and g.b == b0:           # a UNet without any transformer in its encoder
             h, g = widen(h), Geom(b, g.t, g.h, g.w)
@@ -1180,7 +1201,7 @@ class UNetModel(nn.Module, _Prepared):
         for i, block in enumerate(self.output_blocks):
             skip, _ = hs.pop()
             h, h16 = ops.concat_rows(h, skip, with_bf16=True)   # the bf16 copy feeds the ResBlock's 1x1 skip convolution
-            h, g = run(block, h, g, int(math.log2(self.output_ds[i])), h16)
+            h, g = run(block, h, g, int(math.log2(self.output_ds[i])), h16, after=self.out_norm_marker if i + 1 == len(self.output_blocks) else None)
         y = ops.groupnorm(h, pk["gn_g"], pk["gn_b"], instances=g.b * g.t, eps=1e-5, silu=True)
         y = ops.gemm(y, pk["w_out"], k=mc, taps=9, bias=pk["b_out"], out_f32=True, gather=ops.GATHER_CONV3X3,
                      conv=(g.h, g.w, g.h, g.w, 1, 0))

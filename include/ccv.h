@@ -107,10 +107,10 @@ typedef struct CcvGemm {
     int64_t ws_bytes;
     int32_t split_k;        /* set by the library; callers leave it 0 */
     /* GroupNorm statistics of the OUTPUT, produced in the epilogue (the GroupNorm(32) that follows a ResBlock / temporal
-     * convolution, openaimodel3d.py:175-182,210-236,255-266, lvdm/basics.py:78-91): NULL, or [M / gn_rows][gn_slots][32][2] fp32
-     * = per instance (gn_rows consecutive output rows) and output tile the sums and sums of squares of every group's
-     * channels as stored (bf16-rounded), in the layout ccv_groupnorm_apply_parts() reads.  gn_slots must be what
-     * ccv_gemm_gn_slots() returns for this problem (bf16 output, no split-K, tile rows dividing gn_rows). */
+     * convolution / transformer, openaimodel3d.py:175-182,210-236,255-266, attention.py:273,343, lvdm/basics.py:78-91): NULL, or
+     * [M / gn_rows][gn_slots][32][2] fp32 = per instance (gn_rows consecutive output rows) and slot (an output tile, or a row band of
+     * the split-K reduce pass) the sums and sums of squares of every group's channels as stored (rounded to the output type, residual
+     * added), in the layout ccv_groupnorm_apply_parts() reads.  gn_slots must be what ccv_gemm_gn_slots() returns for this problem. */
     float* gn_partial;
     int32_t gn_rows, gn_slots;
     int32_t res_f16;        /* 0: residual is fp32, 1: residual is fp16 (the residual stream's hand-off format between blocks:
@@ -131,8 +131,8 @@ int ccv_gemm(const CcvGemm* p, void* stream);
  * *split = split-K factor. */
 int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
 /* Slots per instance the epilogue statistics of this problem would take (see gn_partial), 0 when the kernel ccv_gemm would run
- * cannot produce them (fp32 output, GEGLU, split-K, A-stationary / register-staged kernels, tile rows not dividing the
- * instance, more than 512 slots): the caller then runs ccv_groupnorm as usual. */
+ * cannot produce them (GEGLU / activation epilogues, fp32 activations, the A-stationary kernel, tiles without a statistics
+ * instance, tile rows not dividing the instance, more than 512 slots): the caller then runs ccv_groupnorm as usual. */
 int32_t ccv_gemm_gn_slots(const CcvGemm* p, int32_t rows_per_instance);
 
 /* ------------------------------------------------------------------------------------
@@ -218,6 +218,8 @@ int ccv_groupnorm(const void* x, int32_t x_f32, uint16_t* y, const float* gamma,
  * laid out [instances][ccv_groupnorm_chunks(...)][32 groups][2]; the caller reduces them over chunks and ranks, writes the totals
  * into chunk 0 (zeros elsewhere) and calls ccv_groupnorm_apply with inv_count = 1 / (elements per group over ALL ranks). */
 int32_t ccv_groupnorm_chunks(int32_t instances, int32_t rows_per_instance, int32_t C);
+/* 1 when ccv_groupnorm runs this problem as a single launch (small slices: 8x8 / 4x4 latents): epilogue statistics save nothing there. */
+int32_t ccv_groupnorm_single_launch(int32_t instances, int32_t rows_per_instance, int32_t C, int32_t x_kind);
 int ccv_groupnorm_stats(const void* x, int32_t x_f32, int32_t instances, int32_t rows_per_instance, int32_t C, void* ws, void* stream);
 int ccv_groupnorm_apply(const void* x, int32_t x_f32, uint16_t* y, const float* gamma, const float* beta, int32_t instances,
                         int32_t rows_per_instance, int32_t C, float eps, int32_t silu, const void* ws, float inv_count, void* stream);

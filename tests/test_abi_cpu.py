@@ -96,10 +96,14 @@ def test_gemm_epilogue_groupnorm_slots_host_logic(built):
     assert _gn_slots(built, 32768, 320, 320, 1024, taps=9, gather=1) == 8 * 2        # ResBlock conv at 32x32 latents: 128x160 tiles, a frame = 8 row tiles
     assert _gn_slots(built, 32768, 320, 320, 16384, taps=3, gather=2) > 128           # temporal conv, clip-wide norm: every tile of the clip a slot (<= 512)
     assert _gn_slots(built, 32768, 320, 320, 16384, taps=3, gather=2) <= 512
-    assert _gn_slots(built, 8192, 640, 1280, 256, taps=9, gather=1) == 0              # split-K plan: the reduce kernel owns the epilogue
-    assert _gn_slots(built, 32768, 320, 320, 1024, taps=9, gather=1, out_f32=1) == 0  # fp32 output: not a GroupNorm input of this path
+    assert _gn_slots(built, 8192, 640, 1280, 256, taps=9, gather=1) == 8              # split-K plan: the reduce pass emits them, 32 rows per workgroup (256 workgroups)
+    assert _gn_slots(built, 8192, 640, 1280, 4096, taps=9, gather=1) == 128           # ... clip-wide instance of the same layer
+    assert _gn_slots(built, 512, 1280, 1280, 256, taps=9, gather=1) == 128            # 4x4 latents: 2 rows per workgroup
+    assert _gn_slots(built, 32768, 320, 320, 1024, taps=9, gather=1, out_f32=2) == 8 * 2   # fp16 (stream) output: same tiles
+    assert _gn_slots(built, 8192, 640, 640, 4096) == 64 * 5                           # transformer proj_out at 16x16 latents, clip-wide consumer: 64x128 tiles
     assert _gn_slots(built, 32768, 320, 320, 1000, taps=9, gather=1) == 0             # instance rows not whole tiles
     assert _gn_slots(built, 32768, 960, 320, 1024) == 0                               # A-stationary kernel
+    assert _gn_slots(built, 8192, 5120, 640, 256, geglu=1) == 0                       # GEGLU epilogue
 
 
 def test_gemm_planner_host_logic(built):

@@ -541,8 +541,9 @@ def test_groupnorm_statistics_from_the_conv_epilogue(ops, frames, side, cin, cou
     h0 = ops.gemm(x, w, **kw)
     assert torch.equal(h, h0)
     y0 = ops.groupnorm(h0, gamma, beta, instances=frames, eps=1e-5, silu=True)
-    if st is None:
-        assert plan[1] > 1, f"no epilogue statistics although the plan {plan} does not split K"
+    if st is None:       # only where the norm itself is a single launch (small slices): statistics from the producer would save nothing
+        from camc2v_amd.lib import lib
+        assert lib().ccv_groupnorm_single_launch(frames, side * side, cout, 0) == 1, f"no epilogue statistics (plan {plan})"
         return
     part, gn_rows = st
     assert gn_rows == side * side and part.shape[0] == frames and part.shape[2] == 64
@@ -955,3 +956,66 @@ def test_concat_and_cast_fp16_rows(ops):
     assert out.dtype == torch.float16 and torch.equal(out, ref)
     assert torch.equal(out16, ref.float().to(torch.bfloat16))
     assert torch.equal(ops.cast_bf16(a), a.float().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", ["conv_res_clip_splitk", "tconv_res_frame", "linear_res_clip", "linear_splitk_clip", "conv_bf16_splitk_frame"])
+def test_groupnorm_statistics_from_stream_epilogues(ops, case):
+    """Round 3: statistics from every producer flavour the UNet has -- residual added, fp16 (stream) or bf16 output, linear /
+    3x3 / temporal gathers, the tile epilogue and the split-K reduce pass: the output must equal the plain call's bit for bit, the
+    slots must add up to the sums of the stored values, and the norm on them must match the norm that makes its own pass."""
+    from camc2v_amd import pack
+    g = torch.Generator().manual_seed(70)
+    if case == "conv_res_clip_splitk":          # ResBlock conv2 + skip at 16x16 latents -> temporal block's first norm (clip-wise)
+        b, t, side, cin, cout = 2, 16, 16, 640, 640
+        rows, inst_rows = b * t * side * side, t * side * side
+        x = rnd(rows, cin, seed=71)
+        w = pack.pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=g) * 0.02).to(dev()))
+        kw = dict(k=cin, taps=9, gather=ops.GATHER_CONV3X3, conv=(side, side, side, side, 1, 0), out_dtype=torch.float16,
+                  residual=rnd(rows, cout, seed=72, dtype=torch.float32).to(torch.float16))
+    elif case == "tconv_res_frame":             # last temporal convolution + block input at 32x32 latents -> SpatialTransformer norm (frame-wise)
+        b, t, side, cin, cout = 2, 16, 32, 320, 320
+        rows, inst_rows = b * t * side * side, side * side
+        x = rnd(rows, cin, seed=71)
+        w = pack.pack_tconv3((torch.randn(cout, cin, 3, 1, 1, generator=g) * 0.03).to(dev()))
+        kw = dict(k=cin, taps=3, gather=ops.GATHER_TCONV3, tconv=(t, side * side), out_dtype=torch.float16,
+                  residual=rnd(rows, cout, seed=72, dtype=torch.float32).to(torch.float16))
+    elif case == "linear_res_clip":             # SpatialTransformer proj_out + input at 16x16 latents -> TemporalTransformer norm (clip-wise)
+        rows, inst_rows, cin, cout = 8192, 4096, 640, 640
+        x = rnd(rows, cin, seed=71)
+        w = rnd(cout, cin, seed=73, scale=0.04)
+        kw = dict(out_dtype=torch.float16, residual=rnd(rows, cout, seed=72, dtype=torch.float32).to(torch.float16))
+    elif case == "linear_splitk_clip":          # a long-K projection whose plan splits K, 8x8 latents, clip-wise consumer
+        rows, inst_rows, cin, cout = 2048, 1024, 5120, 1280
+        x = rnd(rows, cin, seed=71)
+        w = rnd(cout, cin, seed=73, scale=0.02)
+        kw = dict(out_dtype=torch.float16, residual=rnd(rows, cout, seed=72, dtype=torch.float32).to(torch.float16))
+    else:                                       # ResBlock conv1 (+ per-clip embedding) at 16x16 latents, split-K -> second norm (frame-wise), bf16
+        b, t, side, cin, cout = 2, 16, 16, 1280, 640
+        rows, inst_rows = b * t * side * side, side * side
+        x = rnd(rows, cin, seed=71)
+        w = pack.pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=g) * 0.02).to(dev()))
+        emb = rnd(2, cout, seed=74, dtype=torch.float32) * 0.2
+        kw = dict(k=cin, taps=9, gather=ops.GATHER_CONV3X3, conv=(side, side, side, side, 1, 0), bias2=emb, ldb2=emb.stride(0), rows_per_batch=rows // 2)
+    bias = rnd(cout, seed=75, dtype=torch.float32) * 0.1
+    gamma, beta = 1.0 + rnd(cout, seed=76, dtype=torch.float32) * 0.1, rnd(cout, seed=77, dtype=torch.float32) * 0.1
+    inst = rows // inst_rows
+    ops.TRACK_GEMM_PLAN = True
+    try:
+        h, st = ops.gemm(x, w, bias=bias, gn_rows=inst_rows, **kw)
+        plan = ops.LAST_GEMM_PLAN
+    finally:
+        ops.TRACK_GEMM_PLAN = False
+    assert st is not None, f"{case}: no epilogue statistics (plan {plan})"
+    if "splitk" in case:
+        assert plan[1] > 1, f"{case}: expected a split-K plan, got {plan}"
+    h0 = ops.gemm(x, w, bias=bias, **kw)
+    assert torch.equal(h, h0), f"{case}: the statistics-emitting epilogue stores other values"
+    part, gn_rows = st
+    hv = h.float().reshape(inst, inst_rows, 32, cout // 32)
+    want = torch.stack([hv.sum((1, 3)), (hv * hv).sum((1, 3))], -1).reshape(inst, 64)
+    assert_close(part.sum(1), want, 3e-4, f"{case}: epilogue statistics")
+    y0 = ops.groupnorm(h0, gamma, beta, instances=inst, eps=1e-5, silu=True)
+    y = ops.groupnorm(ops.tag_stats(h, st), gamma, beta, instances=inst, eps=1e-5, silu=True)     # picked up from the tag
+    d = (y.float() - y0.float()).abs()
+    assert d.max().item() <= 2.0 ** -6 * max(1.0, y0.float().abs().max().item()), d.max().item()
+    assert (d > 0).float().mean().item() < 0.02

@@ -503,3 +503,63 @@ def test_fp8_epipolar_attention_in_model(golden_dir, monkeypatch):
     _check(y16, fx["y_cam_rep"], "medium, bf16 epipolar attention vs reference fixture", 2.5e-2, 5e-2)
     _check(y8, fx["y_cam_rep"], "medium, e4m3 epipolar attention vs reference fixture", 3e-2, 6e-2)
     _check(y8, y16, "e4m3 vs bf16 epipolar attention in the model", 2.5e-2, 6e-2)
+
+
+def test_config4_as_written_32_frames_cfg_3p5_fp8_medium(golden_dir, monkeypatch):
+    """BASELINE.json configs[4] as written -- a 32-frame clip at CFG 3.5 with the e4m3 (fp8 MFMA) epipolar attention, all three
+    together -- at the medium width (model_channels 128, 16x16 latents: epipolar attention over L = 32 * 256 = 8192 tokens, context
+    rule 77 + 16 * 32 on both CFG passes): a 2-step DDIM trajectory (guidance_rescale 0.7, eta 0) through
+    `model.camcontexti2v.CamContextI2V` + DDIMSampler against the fp32 oracle UNet + oracle sampler on the host.  Stated tolerance:
+    rel-L2 of the final latents <= 6e-2 (bf16 attention on the same case: printed beside it; guidance amplifies the per-forward
+    error by ~(1 + 2 * 3.5 * rescale))."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import unet as unet_mod
+    from oracle import ddim_oracle, unet_oracle
+    from oracle.golden_inputs import MEDIUM_CFG, SEED, small_inputs
+    from utils.utils import instantiate_from_config
+    dev = torch.device("cuda:0")
+    T, steps, scale = 32, 2, 3.5
+    man = json.load(open(os.path.join(golden_dir, "unet_medium_manifest.json")))
+    sd = unet_oracle.seeded_state_dict(man, SEED)
+    inp = small_inputs(b=1, T=T, hl=16, seed=SEED + 40, chans=(128, 256, 512, 512))
+    masks = _oracle_masks(T, 128)
+    g = torch.Generator().manual_seed(4 * T)
+    ctx_uc = torch.randn(1, 77 + 16 * T, 1024, generator=g)
+    cam_cpu = dict(pluker_embedding_features=inp["feats"], sample_locs_dict=masks,
+                   cond_frame_index=torch.zeros(1, dtype=torch.long), add_type="add_to_main_branch")
+
+    def eps(ctx):
+        return lambda x, t: unet_oracle.unet_forward(sd, MEDIUM_CFG, torch.cat([x, inp["c_concat"]], 1), t, ctx, inp["fs"], cam_cpu, origin_h=128)
+
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref, _ = ddim_oracle.ddim_sample(eps(inp["ctx_pf"]), eps(ctx_uc), inp["x_T"], steps, 0.0, scale, 0.7, None)
+    core = instantiate_from_config({"target": "model.camcontexti2v.CamContextI2V", "params": dict(
+        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": dict(MEDIUM_CFG)},
+        linear_start=0.00085, linear_end=0.012, conditioning_key="hybrid", channels=4, image_size=[16, 16], temporal_length=T,
+        add_type="add_to_main_branch",
+        pose_encoder_config={"target": "model.modules.camera_pose_encoder.CameraPoseEncoder", "params": {}},
+        epipolar_config=dict(origin_h=128, origin_w=128, is_3d_full_attn=False, num_register_tokens=4,
+                             attention_resolution=[8, 4, 2, 1], compression_factor=1))})
+    core.model.diffusion_model.load_state_dict(sd, strict=True)
+    core = core.to(dev).eval()
+    to = lambda t: t.to(dev)
+    cam = dict(pluker_embedding_features=[to(f) for f in inp["feats"]], sample_locs_dict={d: to(m) for d, m in masks.items()},
+               cond_frame_index=torch.zeros(1, dtype=torch.long, device=dev), add_type="add_to_main_branch")
+    cc = to(inp["c_concat"])
+
+    def sample():
+        cond = dict(c_concat=[cc], c_crossattn=[to(inp["ctx_pf"])], camera_condition=cam)
+        uncond = dict(c_concat=[cc], c_crossattn=[to(ctx_uc)])
+        out, _ = core.sample_log(cond, 1, True, steps, eta=0.0, x_T=inp["x_T"], unconditional_guidance_scale=scale,
+                                 unconditional_conditioning=uncond, timestep_spacing="uniform_trailing", guidance_rescale=0.7,
+                                 fs=to(inp["fs"]), enable_camera_condition=True)
+        return out
+
+    x16 = sample()
+    monkeypatch.setattr(unet_mod, "FP8_EPIPOLAR", True)
+    x8 = sample()
+    assert not torch.equal(x8, x16)                  # the e4m3 kernel did run (L = 8192 >= FP8_EPIPOLAR_MIN_TOKENS)
+    _check(x16, ref.numpy(), "configs[4] medium, 32 frames, CFG 3.5, bf16 epipolar attention: 2-step trajectory vs oracle", 6e-2, 1.5e-1)
+    _check(x8, ref.numpy(), "configs[4] medium, 32 frames, CFG 3.5, e4m3 epipolar attention: 2-step trajectory vs oracle", 6e-2, 1.5e-1)
