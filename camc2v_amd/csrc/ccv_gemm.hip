@@ -1119,11 +1119,14 @@ inline int choose_split(const CcvGemm& p) {
     return s < 2 ? 1 : (int)s;
 }
 
+thread_local int g_plan_stages = 0;     // LDS stages the current plan asks for (0 = family_stages' rule); set by dispatch_tile
+
 // LDS stages of the family kernel for a problem (gemm_dma_kernel: 2 = two-stage loop, 3 / 4 = ring with counted waits).
 // CCV_GEMM_ST (tuning aid, with CCV_GEMM_TUNE=1 re-read per call): 2 / 3 force a depth, 0 / unset = the rule below.
 inline int family_stages(const CcvGemm& p, int bm, int bn) {
     const int forced = tune_env("CCV_GEMM_ST");
     if (forced >= 2 && forced <= 4) return forced;
+    if (g_plan_stages >= 2) return g_plan_stages;
     static const int env = [] { const char* e = getenv("CCV_GEMM_ST"); return e ? atoi(e) : 0; }();
     if (env >= 2 && env <= 4) return env;
     const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * (p.split_k > 1 ? p.split_k : 1);
@@ -1234,6 +1237,8 @@ struct Plan {
     int ring;    // index into kRing, -1: 128x128-family kernels (gemm_dma_kernel / gemm_kernel) with the tile choose_tile
                  // picks, FAM_128x160 / FAM_64x160: the family kernel on a 160-column tile
     int split;   // split-K factor (1 = none)
+    int famtile = 0;   // ring == -1 only: 0 = the tile choose_tile picks, else 10 MT + NT of the family tile (44 / 24 / 42 / 22 / 45 / 25)
+    int stages = 0;    // family kernel: 0 = family_stages' rule, 2 / 3 = LDS stages
 };
 constexpr int FAM_128x160 = -2, FAM_64x160 = -3;   // (64x160: reachable through CCV_GEMM_FAMTILE=25 only)
 
@@ -1257,6 +1262,38 @@ inline bool ring_fits(const CcvGemm& p, int r) {
 //  * 3x3 / temporal convolutions: long K (>= 256 slabs of 32) on the 2-stage 128x320 tile with split-K up to ~512
 //    workgroups (up to 910 TFLOP/s), shorter K on the 128x160 ring tile (with split-K to reach 256-512 workgroups
 //    on the 16x16 .. 4x4 latent layers).
+// Per-shape plans from the cold-operand sweep (tools/plan_sweep.py, profiles/r03_gemm_plan_sweep.txt: every family tile x LDS
+// stages x split-K and every ring tile x split-K per GEMM signature of the CFG-pair forward, weights and activations rotating
+// through > 256 MB of copies).  Listed: signatures whose best plan beat the rules below by >= 5 %; K = -1 matches any K.
+// CCV_GEMM_TABLE=0 (A/B aid) ignores the table.
+struct PlanRow { int M, N, K, taps, gather, res; Plan plan; };     // res: -1 any, 0 without / 1 with a residual operand
+inline const Plan* plan_override(const CcvGemm& p) {
+    static const PlanRow rows[] = {
+        {8192, 1920, 640, 1, 0, -1, {6, 1}},                    // QKV projection, 16x16 latents: 2-deep 128x160 ring      42.2 -> 37.1 us
+        {2048, 1280, 1280, 3, 2, 0, {-1, 1, 25, 3}},            // temporal conv, 8x8: 64x160 tile, 3 stages, no split-K     46.1 -> 39.1
+        {2048, 1280, 1280, 3, 2, 1, {-1, 4, 45, 2}},            // ... the one that updates the stream                      46.2 -> 40.9
+        {32768, 320, 1280, 1, 0, -1, {-1, 1, 45, 2}},           // feed-forward down-projection, 32x32: 128x160 tile        63.4 -> 49.8
+        {2048, 1280, 1280, 1, 0, -1, {-1, 1, 42, 3}},           // K = C projections, 8x8: 128x64 tile, 3 stages            23.0 -> 21.2
+        {2048, 1280, 2560, 1, 0, -1, {-1, 1, 42, 3}},           // skip convolution 1x1, 8x8                                37.3 -> 30.4
+        {8192, 640, 640, 3, 2, 0, {-1, 1, 45, 3}},              // temporal conv, 16x16                                     36.6 -> 34.6
+        {8192, 640, 2560, 1, 0, -1, {-1, 1, 45, 3}},            // feed-forward down-projection, 16x16                      56.3 -> 47.7
+        {2048, 1280, 5120, 1, 0, -1, {-1, 2, 45, 3}},           // ... 8x8                                                  50.1 -> 47.7
+        {8192, 640, -1, 9, 1, -1, {-1, 2, 45, 2}},              // 3x3 convolutions, 16x16 (K = 640 ... 1920): 128x160 x 2  91 -> 74, 111 -> 96, 139 -> 128, 188 -> 177
+        {2048, 1280, 1280, 3, 3, -1, {-1, 2, 45, 3}},           // stacked camera projections, 8x8                          48.4 -> 41.2
+        {8192, 640, 640, 3, 3, -1, {-1, 1, 45, 3}},             // ... 16x16                                                45.0 -> 39.8
+        {512, 1280, -1, 9, 1, -1, {-1, 8, 45, 3}},              // 3x3 convolutions, 4x4: 128x160 tile, 3 stages, split 8    34.8 -> 32.9, 53.9 -> 49.7
+        {512, 1280, 5120, 1, 0, -1, {-1, 4, 25, 3}},            // feed-forward down-projection, 4x4                        27.0 -> 23.0
+        {8192, 640, 640, 1, 0, 0, {-1, 1, 45, 3}},              // proj_in, 16x16                                           19.3 -> 18.3
+    };
+    static const bool on = [] { const char* e = getenv("CCV_GEMM_TABLE"); return !(e && e[0] == '0'); }();
+    if (!on || p.a_f32 || p.geglu) return nullptr;
+    for (const PlanRow& r : rows)
+        if (r.M == p.M && r.N == p.N && (r.K < 0 || r.K == p.K) && r.taps == p.taps && r.gather == p.gather &&
+            (r.res < 0 || r.res == (p.residual != nullptr ? 1 : 0)))
+            return &r.plan;
+    return nullptr;
+}
+
 inline Plan make_plan(const CcvGemm& p, bool allow_split) {
     static const bool ring_on = [] { const char* e = getenv("CCV_GEMM_WIDE"); return !(e && e[0] == '0'); }();
     const int forced_ring = tune_env("CCV_GEMM_RING"), forced_split = tune_env("CCV_GEMM_SPLIT");
@@ -1276,6 +1313,13 @@ inline Plan make_plan(const CcvGemm& p, bool allow_split) {
         if (sp > 16) sp = 16;
         return Plan{r, sp < 1 ? 1 : sp};
     };
+    if (forced_ring == -2 && forced_split <= 0 && tune_env("CCV_GEMM_FAMTILE") == -2 && tune_env("CCV_GEMM_ST") == -2) {
+        if (const Plan* ov = plan_override(p)) {
+            Plan pl = *ov;
+            if (!allow_split) pl.split = 1;
+            if (pl.ring < 0 || ring_fits(p, pl.ring)) return pl;
+        }
+    }
     if (forced_ring == -1 || !ring_on || p.a_f32) return family();
     if (forced_ring >= 0) return ring_fits(p, forced_ring) ? ring(forced_ring, forced_split > 0 ? forced_split : 1) : family();
     const long tiles0 = (long)((p.M + 127) / 128) * (p.N / 320);   // 128x320 tiles (meaningful when N % 320 == 0)
@@ -1324,6 +1368,12 @@ inline int slab_depth_override() {  // CCV_GEMM_BK=32|64 forces the slab depth (
     return v;
 }
 
+// the family tile of a plan: the table's, else what choose_tile picks
+inline void plan_tile(const CcvGemm& p, const Plan& pl, int& mt, int& nt) {
+    if (pl.ring == -1 && pl.famtile > 0) { mt = pl.famtile / 10; nt = pl.famtile % 10; return; }
+    choose_tile(p, mt, nt);
+}
+
 template <int GATHER>
 int dispatch_ring(const CcvGemm& p, int ring, hipStream_t st) {
     switch (ring) {
@@ -1339,9 +1389,11 @@ int dispatch_ring(const CcvGemm& p, int ring, hipStream_t st) {
 }
 
 template <bool A_F32, int GATHER>
-int dispatch_tile(const CcvGemm& p, int ring, hipStream_t st) {
+int dispatch_tile(const CcvGemm& p, const Plan& pl, hipStream_t st) {
+    const int ring = pl.ring;
     int mt, nt;
-    choose_tile(p, mt, nt);
+    plan_tile(p, pl, mt, nt);
+    g_plan_stages = pl.stages;
     if (!A_F32 && ring >= 0) return dispatch_ring<GATHER>(p, ring, st);
     if (!A_F32 && ring == FAM_128x160) return launch_dma<4, 5, GATHER>(p, st);
     if (!A_F32 && ring == FAM_64x160) return launch_dma<2, 5, GATHER>(p, st);
@@ -1661,6 +1713,9 @@ inline int choose_tile_order(const CcvGemm& p) {
     const double w_bytes = (double)p.N * p.taps * p.K * 2.0;
     // measured (tools/order_probe.py, cold weights): M-fastest pays only where the weights dwarf the activations -- the M = 512 layers
     // of the 4x4 latents, -3 ... -18 %; at M = 2048 (weights 2-20x the activations) it costs 1-7 %, at M = 8192 up to 20 %
+    static const int rule = [] { const char* e = getenv("CCV_GEMM_ORDER_RULE"); return e ? atoi(e) : 0; }();   // A/B aid: 1 = wherever the weights are larger
+    if (rule == 1) return w_bytes > a_bytes ? 1 : 0;
+    if (rule == 2) return (w_bytes >= 2.0 * a_bytes && p.M <= 4096) ? 1 : 0;
     return (w_bytes >= 2.0 * a_bytes && p.M <= 1024) ? 1 : 0;
 }
 
@@ -1704,7 +1759,7 @@ static bool gn_tile_dims(const CcvGemm& p, const Plan& pl, int& bm, int& bn) {
     if (pl.ring == FAM_128x160) { mt = 4; nt = 5; }
     else if (pl.ring == FAM_64x160) { mt = 2; nt = 5; }
     else if (!dma_enabled()) return false;
-    else choose_tile(p, mt, nt);
+    else plan_tile(p, pl, mt, nt);
     bm = 32 * mt;
     bn = 32 * nt;
     return gn_dma_tile(mt, nt, p.gather);
@@ -1746,7 +1801,7 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     }
     p.split_k = pl.split;
     p.tile_order = choose_tile_order(p);
-    const int ring = pl.ring;
+    (void)pl.ring;
     CCV_REQUIRE(p.A && p.W && p.C, CCV_EINVAL, "ccv_gemm: null A/W/C");
     CCV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, CCV_EINVAL, "ccv_gemm: non-positive M/N/K (%d,%d,%d)", p.M, p.N, p.K);
     CCV_REQUIRE(p.K % BK == 0, CCV_ESHAPE, "ccv_gemm: K=%d must be a multiple of 64", p.K);
@@ -1767,25 +1822,25 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     switch (p.gather) {
         case 0:
             CCV_REQUIRE(p.taps == 1, CCV_EINVAL, "ccv_gemm: linear gather needs taps == 1");
-            return p.a_f32 ? dispatch_tile<true, 0>(p, ring, st) : dispatch_tile<false, 0>(p, ring, st);
+            return p.a_f32 ? dispatch_tile<true, 0>(p, pl, st) : dispatch_tile<false, 0>(p, pl, st);
         case 1:
             CCV_REQUIRE(p.taps == 9, CCV_EINVAL, "ccv_gemm: conv3x3 gather needs taps == 9");
             CCV_REQUIRE(p.out_h > 0 && p.out_w > 0 && p.src_h > 0 && p.src_w > 0 && (p.stride == 1 || p.stride == 2) &&
                             (p.upsample == 0 || p.upsample == 1) && p.M % (p.out_h * p.out_w) == 0,
                         CCV_EINVAL, "ccv_gemm: bad conv geometry");
-            return p.a_f32 ? dispatch_tile<true, 1>(p, ring, st) : dispatch_tile<false, 1>(p, ring, st);
+            return p.a_f32 ? dispatch_tile<true, 1>(p, pl, st) : dispatch_tile<false, 1>(p, pl, st);
         case 2:
             CCV_REQUIRE(p.taps == 3, CCV_EINVAL, "ccv_gemm: tconv3 gather needs taps == 3");
             CCV_REQUIRE(p.frames > 0 && p.hw > 0 && p.M % (p.frames * p.hw) == 0, CCV_EINVAL, "ccv_gemm: bad tconv geometry");
             CCV_REQUIRE(!p.a_f32, CCV_ESHAPE, "ccv_gemm: tconv3 takes bf16 activations");
-            return dispatch_tile<false, 2>(p, ring, st);
+            return dispatch_tile<false, 2>(p, pl, st);
         case 3:
             // stacked operand: A = [taps][hw rows][lda], out[m] = sum_t A[t][m] . W[:, t*K:(t+1)*K]^T -- several linear maps
             // into the same output (e.g. the three projections a camera-conditioned temporal block adds to its stream,
             // modified_forwards.py:519-529) as ONE GEMM with one epilogue
             CCV_REQUIRE(p.taps >= 1 && p.hw >= p.M, CCV_EINVAL, "ccv_gemm: segment gather needs taps >= 1 and a segment stride (hw) >= M");
             CCV_REQUIRE(!p.a_f32, CCV_ESHAPE, "ccv_gemm: segment gather takes bf16 activations");
-            return dispatch_tile<false, 3>(p, ring, st);
+            return dispatch_tile<false, 3>(p, pl, st);
         default:
             ccv_set_error("ccv_gemm: unknown gather %d", p.gather);
             return CCV_EINVAL;

@@ -100,7 +100,7 @@ def test_gemm_epilogue_groupnorm_slots_host_logic(built):
     assert _gn_slots(built, 8192, 640, 1280, 4096, taps=9, gather=1) == 128           # ... clip-wide instance of the same layer
     assert _gn_slots(built, 512, 1280, 1280, 256, taps=9, gather=1) == 128            # 4x4 latents: 2 rows per workgroup
     assert _gn_slots(built, 32768, 320, 320, 1024, taps=9, gather=1, out_f32=2) == 8 * 2   # fp16 (stream) output: same tiles
-    assert _gn_slots(built, 8192, 640, 640, 4096) == 64 * 5                           # transformer proj_out at 16x16 latents, clip-wide consumer: 64x128 tiles
+    assert _gn_slots(built, 8192, 640, 640, 4096) == 32 * 4                           # transformer proj_in / proj_out at 16x16 latents, clip-wide consumer: 128x160 tiles (plan table)
     assert _gn_slots(built, 32768, 320, 320, 1000, taps=9, gather=1) == 0             # instance rows not whole tiles
     assert _gn_slots(built, 32768, 960, 320, 1024) == 0                               # A-stationary kernel
     assert _gn_slots(built, 8192, 5120, 640, 256, geglu=1) == 0                       # GEGLU epilogue
@@ -113,18 +113,18 @@ def test_gemm_planner_host_logic(built):
     assert _plan(built, 32768, 2560, 320, geglu=1) == (-4, 1)            # GEGLU up-projection there: the same
     assert _plan(built, 16384, 960, 320) == (-1, 1)                      # a single (not CFG-paired) forward: 128 row tiles would idle half the chip
     assert _plan(built, 8192, 5120, 640, geglu=1) == (5, 1)              # GEGLU up-projection at 16x16 latents: 2-stage 128x320 tile
-    assert _plan(built, 8192, 1920, 640) == (-1, 1)                      # QKV projection at 16x16 latents: 128x128 family, unsplit
+    assert _plan(built, 8192, 1920, 640) == (6, 1)                       # QKV projection at 16x16 latents: 2-deep 128x160 ring (cold-operand sweep table)
     assert _plan(built, 512, 10240, 1280, geglu=1) == (-1, 1)            # ... unless its 128 tiles would leave CUs idle
-    assert _plan(built, 2048, 1280, 5120) == (-2, 4)                     # FF down-projection at 8x8 latents: long K -> 128x160 family tile, split 4
+    assert _plan(built, 2048, 1280, 5120) == (-1, 2)                     # FF down-projection at 8x8 latents: 128x160 family tile, 3 stages, split 2 (table)
     assert _plan(built, 512, 1280, 5120) == (-1, 4)                      # ... at 4x4 latents: 160 tiles, split-K 4
     assert _plan(built, 32768, 320, 320, taps=9, gather=1) == (-2, 1)    # conv3x3 at 32x32 latents: 128x160 family tile (128-byte rows)
     assert _plan(built, 32768, 320, 960, taps=9, gather=1) == (-2, 1)
-    assert _plan(built, 8192, 640, 1280, taps=9, gather=1) == (5, 4)     # 16x16 latents, long K: 128x320 tiles, 2 per CU, split to 512
-    assert _plan(built, 8192, 640, 640, taps=9, gather=1) == (2, 2)
+    assert _plan(built, 8192, 640, 1280, taps=9, gather=1) == (-1, 2)    # 16x16 latents: 128x160 family tile, split 2 (table)
+    assert _plan(built, 8192, 640, 640, taps=9, gather=1) == (-1, 2)
     assert _plan(built, 2048, 1280, 2560, taps=9, gather=1) == (-2, 4)   # 8x8 latents: 128 tiles of 128x160 x split 4
-    assert _plan(built, 512, 1280, 1280, taps=9, gather=1) == (2, 8)     # 4x4 latents: 32 tiles x 8 splits
+    assert _plan(built, 512, 1280, 1280, taps=9, gather=1) == (-1, 8)    # 4x4 latents: 32 tiles of 128x160 (3 stages) x 8 splits (table)
     assert _plan(built, 32768, 320, 320, taps=3, gather=2) == (-2, 1)
-    assert _plan(built, 2048, 1280, 1280, taps=3, gather=2) == (-1, 2)
+    assert _plan(built, 2048, 1280, 1280, taps=3, gather=2) == (-1, 1)   # temporal conv at 8x8 latents: 64x160 tile, 3 stages, unsplit (table)
     assert _plan(built, 512, 1280, 1280, taps=3, gather=2) == (-1, 3)
     assert _plan(built, 32768, 512, 2048) == (-1, 1)                     # N not a multiple of 160: never a ring tile
     assert _plan(built, 2048, 1280, 2560, a_f32=1)[0] == -1              # fp32 activations: register-staged kernel

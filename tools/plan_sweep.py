@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Kernel plan sweep of ccv_gemm over the GEMM signatures of the benchmark's CFG-pair forward, COLD operands (weights and activations
+rotate through > 256 MB of copies, as inside the model): every family tile x LDS stages x split-K, every ring tile x split-K,
+against what the built-in planner picks.  Feeds the per-shape table of csrc/ccv_gemm.hip (plan_override).
+    CCV_GEMM_TUNE=1 python tools/plan_sweep.py [min_gain_percent]
+"""
+import os
+import sys
+
+os.environ["CCV_GEMM_TUNE"] = "1"
+import torch  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from camc2v_amd import ops, pack  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.set_grad_enabled(False)
+ops.TRACK_GEMM_PLAN = True
+REPS = 36
+F16 = torch.float16
+
+# (kind, M, N, K, flavour, launches per forward)   kind: lin / conv (taps 9) / tconv (taps 3) / seg (3 stacked segments)
+SHAPES = [
+    ("lin", 8192, 5120, 640, "geglu", 10), ("lin", 8192, 1920, 640, "plain", 20), ("lin", 2048, 10240, 1280, "geglu", 10),
+    ("tconv", 2048, 1280, 1280, "plain", 15), ("lin", 2048, 3840, 1280, "plain", 20), ("lin", 32768, 320, 1280, "resb", 10),
+    ("lin", 8192, 640, 640, "res", 25), ("lin", 2048, 1280, 1280, "res", 25), ("tconv", 512, 1280, 1280, "plain", 21),
+    ("tconv", 8192, 640, 640, "plain", 15), ("lin", 8192, 640, 2560, "resb", 10), ("lin", 2048, 1280, 5120, "resb", 10),
+    ("tconv", 32768, 320, 320, "plain", 12), ("conv", 8192, 640, 640, "res", 5), ("conv", 2048, 1280, 1280, "res", 5),
+    ("conv", 32768, 320, 320, "res", 4), ("seg", 32768, 320, 320, "res", 5), ("conv", 2048, 1280, 2560, "plain", 2),
+    ("conv", 32768, 320, 640, "plain", 2), ("tconv", 2048, 1280, 1280, "res", 5), ("conv", 512, 1280, 1280, "res", 7),
+    ("seg", 2048, 1280, 1280, "res", 5), ("lin", 2048, 1280, 1280, "f16", 10), ("lin", 8192, 640, 640, "f16", 10),
+    ("seg", 8192, 640, 640, "res", 5), ("tconv", 8192, 640, 640, "res", 5), ("tconv", 512, 1280, 1280, "res", 7),
+    ("tconv", 32768, 320, 320, "res", 4), ("conv", 8192, 640, 1920, "plain", 1), ("conv", 32768, 320, 960, "plain", 1),
+    ("conv", 512, 1280, 2560, "plain", 3), ("conv", 512, 1280, 1280, "plain", 4), ("conv", 8192, 640, 1280, "plain", 1),
+    ("lin", 512, 1280, 1280, "res", 5), ("conv", 8192, 640, 960, "plain", 1), ("lin", 2048, 1280, 1280, "plain", 5),
+    ("lin", 8192, 640, 640, "plain", 5), ("conv", 2048, 1280, 1920, "plain", 1), ("lin", 512, 3840, 1280, "plain", 4),
+    ("conv", 8192, 640, 640, "plain", 1), ("conv", 32768, 320, 320, "plain", 1), ("conv", 2048, 1280, 1280, "plain", 1),
+    ("lin", 512, 10240, 1280, "geglu", 2), ("lin", 512, 1280, 5120, "resb", 2), ("lin", 2048, 1280, 2560, "f16", 2),
+]
+
+
+def timed_graph(fn_of_i):
+    for i in range(2):
+        fn_of_i(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(REPS):
+            fn_of_i(i)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / REPS)
+    return best
+
+
+def setenv(**kw):
+    for k in ("CCV_GEMM_RING", "CCV_GEMM_SPLIT", "CCV_GEMM_FAMTILE", "CCV_GEMM_ST"):
+        os.environ.pop(k, None)
+    for k, v in kw.items():
+        os.environ[k] = str(v)
+
+
+def build(kind, M, N, K, flavour):
+    taps = {"conv": 9, "tconv": 3, "seg": 3}.get(kind, 1)
+    wbytes, abytes = N * K * taps * 2, M * K * 2 * (taps if kind == "seg" else 1)
+    nw = max(2, min(REPS, (400 << 20) // wbytes + 1))
+    na = max(2, min(REPS, (400 << 20) // abytes + 1))
+    kw = {}
+    if kind == "conv":
+        side = int(round((M // 32) ** 0.5))
+        Ws = [pack.pack_conv3x3(torch.randn(N, K, 3, 3, device=dev) * 0.02) for _ in range(nw)]
+        kw = dict(k=K, taps=9, gather=ops.GATHER_CONV3X3, conv=(side, side, side, side, 1, 0))
+    elif kind == "tconv":
+        Ws = [pack.pack_tconv3(torch.randn(N, K, 3, 1, 1, device=dev) * 0.02) for _ in range(nw)]
+        kw = dict(k=K, taps=3, gather=ops.GATHER_TCONV3, tconv=(16, M // 32))
+    elif kind == "seg":
+        Ws = [(torch.randn(N, 3 * K, device=dev) * 0.03).to(torch.bfloat16) for _ in range(nw)]
+        kw = dict(k=K, taps=3, m=M, gather=ops.GATHER_SEGMENTS, seg_rows=M)
+    else:
+        Ws = [(torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16) for _ in range(nw)]
+    As = [torch.randn(M * (3 if kind == "seg" else 1), K, device=dev).to(torch.bfloat16) for _ in range(na)]
+    bias = torch.zeros(N, device=dev)
+    if flavour == "geglu":
+        kw.update(geglu=True, bias=bias)
+        out = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
+    elif flavour == "res":          # fp16 stream update
+        stream = torch.randn(M, N, device=dev).to(F16)
+        out = torch.empty_like(stream)
+        kw.update(residual=stream, out_dtype=F16, bias=bias)
+    elif flavour == "resb":         # fp16 residual, bf16 out (last feed-forward of a transformer)
+        kw.update(residual=torch.randn(M, N, device=dev).to(F16), bias=bias)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    elif flavour == "f16":
+        kw.update(out_dtype=F16, bias=bias)
+        out = torch.empty(M, N, device=dev, dtype=F16)
+    else:
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    return (lambda i: ops.gemm(As[i % na], Ws[i % nw], out=out, **kw)), 2.0 * M * N * K * taps, out
+
+
+def main():
+    min_gain = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+    total_auto = total_best = 0.0
+    for kind, M, N, K, flavour, count in SHAPES:
+        fn, flops, out = build(kind, M, N, K, flavour)
+        setenv()
+        fn(0)
+        ref = out.float().clone()
+        auto_plan = ops.LAST_GEMM_PLAN
+        t_auto = timed_graph(fn)
+        res = []
+        cands = [dict(CCV_GEMM_RING=-1, CCV_GEMM_FAMTILE=ft, CCV_GEMM_ST=st, CCV_GEMM_SPLIT=sp)
+                 for ft in (44, 24, 42, 22, 45, 25) for st in (2, 3) for sp in (1, 2, 3, 4, 8)]
+        cands += [dict(CCV_GEMM_RING=r, CCV_GEMM_SPLIT=sp) for r in range(8) for sp in (1, 2, 4, 8)]
+        seen = set()
+        for c in cands:
+            setenv(**c)
+            try:
+                fn(0)
+            except Exception:
+                continue
+            plan = ops.LAST_GEMM_PLAN
+            want_split = c["CCV_GEMM_SPLIT"]
+            if plan[1] != want_split or (c["CCV_GEMM_RING"] >= 0 and plan[0] != c["CCV_GEMM_RING"]):
+                continue                                 # the configuration does not apply to this shape
+            key = (c.get("CCV_GEMM_RING"), c.get("CCV_GEMM_FAMTILE"), c.get("CCV_GEMM_ST"), plan[1])
+            if key in seen:
+                continue
+            seen.add(key)
+            err = ((out.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+            if err > 2e-2:
+                print(f"  !! {c} differs from the planner's result by {err:.2e}", flush=True)
+                continue
+            res.append((timed_graph(fn), key))
+        setenv()
+        res.sort()
+        best_t, best_k = res[0]
+        gain = 100.0 * (1.0 - best_t / t_auto)
+        total_auto += t_auto * count
+        total_best += min(best_t, t_auto) * count
+        top = "  ".join(f"{k}:{t:.1f}" for t, k in res[:4])
+        flag = "  <== " if gain >= min_gain else ""
+        print(f"{kind:5s} M={M:6d} N={N:6d} K={K:5d} {flavour:6s} x{count:2d} auto {auto_plan} {t_auto:6.1f} us ({flops / t_auto / 1e6:5.0f} TF/s) | best {best_k} {best_t:6.1f} us "
+              f"({gain:+.0f} %){flag} | {top}", flush=True)
+    print(f"# sum over the forward: planner {total_auto / 1e3:.2f} ms, per-shape best {total_best / 1e3:.2f} ms ({100 * (1 - total_best / total_auto):.1f} % less)")
+
+
+if __name__ == "__main__":
+    main()
