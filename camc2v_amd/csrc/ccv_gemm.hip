@@ -1160,7 +1160,9 @@ int launch_dma(const CcvGemm& p, hipStream_t st) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.split_k > 1 ? p.split_k : 1);
     if (!p.gn_partial || p.split_k > 1) {
         const int stages = family_stages(p, BM, BN);
-        if (stages >= 3) return launch_dma_ring<MT, NT, GATHER, 3>(p, st);     // (4 stages measured equal to 3: not instantiated)
+        if constexpr ((BM + BN) * 128 * 3 <= 160 * 1024) {
+            if (stages >= 3) return launch_dma_ring<MT, NT, GATHER, 3>(p, st);     // (4 stages measured equal to 3: not instantiated)
+        }
     }
     const size_t lds = 2 * (BM + BN) * 128;
     if constexpr (gn_dma_tile(MT, NT, GATHER)) {
@@ -1398,6 +1400,8 @@ int dispatch_tile(const CcvGemm& p, const Plan& pl, hipStream_t st) {
     if (!A_F32 && ring == FAM_128x160) return launch_dma<4, 5, GATHER>(p, st);
     if (!A_F32 && ring == FAM_64x160) return launch_dma<2, 5, GATHER>(p, st);
     if (!A_F32 && dma_enabled()) {
+        // (256-row / 256-column tiles -- 8x4, 4x8, 8x5, 8x8 fragments per wave, one workgroup per CU -- were instantiated for the
+        // round-3 sweep and never came within 10 % of the best plan of any shape: this two-barrier loop needs two waves per SIMD)
         if (mt == 4 && nt == 5) return launch_dma<4, 5, GATHER>(p, st);
         if (mt == 2 && nt == 5) return launch_dma<2, 5, GATHER>(p, st);
         if (mt == 4 && nt == 4) return launch_dma<4, 4, GATHER>(p, st);
@@ -1714,8 +1718,9 @@ inline int choose_tile_order(const CcvGemm& p) {
     // measured (tools/order_probe.py, cold weights): M-fastest pays only where the weights dwarf the activations -- the M = 512 layers
     // of the 4x4 latents, -3 ... -18 %; at M = 2048 (weights 2-20x the activations) it costs 1-7 %, at M = 8192 up to 20 %
     static const int rule = [] { const char* e = getenv("CCV_GEMM_ORDER_RULE"); return e ? atoi(e) : 0; }();   // A/B aid: 1 = wherever the weights are larger
-    if (rule == 1) return w_bytes > a_bytes ? 1 : 0;
-    if (rule == 2) return (w_bytes >= 2.0 * a_bytes && p.M <= 4096) ? 1 : 0;
+    // with a second launch stream busy (ccv_set_streams_in_flight) the fabric traffic saved counts for more than the few percent a
+    // single kernel loses: wherever the weights are larger (in-model A/B on one box: two clips in flight +0.7 %, one clip -0.5 %)
+    if (rule == 1 || (rule == 0 && g_streams_in_flight.load() >= 2)) return w_bytes > a_bytes ? 1 : 0;
     return (w_bytes >= 2.0 * a_bytes && p.M <= 1024) ? 1 : 0;
 }
 

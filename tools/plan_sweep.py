@@ -21,6 +21,7 @@ F16 = torch.float16
 
 # (kind, M, N, K, flavour, launches per forward)   kind: lin / conv (taps 9) / tconv (taps 3) / seg (3 stacked segments)
 SHAPES = [
+    ("lin", 32768, 960, 320, "plain", 20), ("lin", 32768, 2560, 320, "geglu", 10), ("lin", 32768, 320, 320, "res", 25),
     ("lin", 8192, 5120, 640, "geglu", 10), ("lin", 8192, 1920, 640, "plain", 20), ("lin", 2048, 10240, 1280, "geglu", 10),
     ("tconv", 2048, 1280, 1280, "plain", 15), ("lin", 2048, 3840, 1280, "plain", 20), ("lin", 32768, 320, 1280, "resb", 10),
     ("lin", 8192, 640, 640, "res", 25), ("lin", 2048, 1280, 1280, "res", 25), ("tconv", 512, 1280, 1280, "plain", 21),
