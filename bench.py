@@ -196,17 +196,24 @@ def timed_clips(sample_fn, steps, warmup, dist=None, sync=None, after=None, lane
         if errors:
             raise errors[0]
     out = outs.get(steps - 1)
+    sync()
+    own = time.perf_counter() - t0       # this rank's own clips, before any rank waits for another
     extra = after(out) if after is not None else None
     fence()
     mine = time.perf_counter() - t0
     worst = mine
     if dist is not None:
-        tt = torch.tensor([mine], dtype=torch.float64)
+        tt = torch.tensor([mine, own], dtype=torch.float64)
         if torch.cuda.is_available() and dist.get_backend() == "nccl":
             tt = tt.cuda()
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        worst = float(tt.item())
+        every = [torch.empty_like(tt) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, tt)                       # every rank's own wall time (the line reports them all)
+        PER_RANK_S[:] = [float(t[1].item()) for t in every]
+        worst = max(float(t[0].item()) for t in every)
     return worst, mine, out, extra
+
+
+PER_RANK_S = []      # wall seconds every rank spent on its OWN clips of the timed region, before the closing all_gather / barrier
 
 
 def gather_latents(dist, world):
@@ -215,8 +222,12 @@ def gather_latents(dist, world):
     def run(out):
         if dist is None:
             return 1
-        parts = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(parts, out.contiguous())
+        flat = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)     # one buffer, one collective
+        parts = flat.view((world,) + tuple(out.shape))
+        try:
+            dist.all_gather_into_tensor(flat, out.contiguous())
+        except (RuntimeError, NotImplementedError):      # a backend without the tensor form
+            dist.all_gather(list(parts.unbind(0)), out.contiguous())
         sums = [float(p.double().abs().sum()) for p in parts]
         return len({round(s, 3) for s in sums if s == s and s != float("inf")})
     return run
@@ -417,6 +428,8 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
     }
     if ranks_seen is not None:
         line["config"]["ranks_in_final_all_gather"] = ranks_seen
+    if PER_RANK_S:
+        line["config"]["per_rank_ms_per_step"] = [1e3 * t / steps for t in PER_RANK_S]
     return line
 
 
@@ -455,6 +468,8 @@ def main(argv=None, hooks=None):
                     "sharded over them (camc2v_amd/parallel.py; eager, strong scaling); default is one independent clip stream per rank")
     ap.add_argument("--cfg-split", action="store_true", help="single-clip latency mode for 2 ranks: rank 0 runs the conditional, rank 1 the "
                     "unconditional forward of every step (camc2v_amd/parallel.py: CfgSplit; hipGraph per rank, strong scaling)")
+    ap.add_argument("--shard-graph", action="store_true", help="with --frame-shard on RCCL: capture the sharded step, collectives included, "
+                    "into a hipGraph (the exchanges are issued on the compute stream); untested until a multi-GPU node is reachable")
     ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
     args = ap.parse_args(argv)
     hooks = hooks or {}
@@ -505,7 +520,7 @@ def main(argv=None, hooks=None):
         raise SystemExit("bench.py: --cfg-split needs exactly 2 ranks")
     sharded = bool((args.frame_shard or args.cfg_split) and world > 1)     # the ranks sample every clip TOGETHER
     sets = [make_inputs(model, device, rank=0 if sharded else rank, clip=i) for i in range(n_sets)]     # sharded: all ranks work on the same clips
-    use_graph = not args.no_graph and not (sharded and args.frame_shard)
+    use_graph = not args.no_graph and not (sharded and args.frame_shard and not (args.shard_graph and on_gpu and not rehearsal))
     if sharded:
         args.lanes = 1
         if on_gpu and args.frame_shard:

@@ -395,6 +395,39 @@ def groupnorm_sharded(x, gamma, beta, *, instances, eps, silu, reduce_sums, tota
     return y
 
 
+def groupnorm_partial_sums(x, instances):
+    """This process's (sum, sum of squares) per (instance, group) of x [rows, C]: fp32 [instances, 64] (the statistics half of
+    ``groupnorm``; see ``groupnorm_apply_sums``)."""
+    _dev(x)
+    rows, Cc = _rows(x)
+    if rows % instances:
+        raise CcvError("groupnorm_partial_sums: rows not divisible by instances")
+    rpi = rows // instances
+    nchunk = lib().ccv_groupnorm_chunks(instances, rpi, Cc)
+    ws = torch.empty(lib().ccv_groupnorm_ws_bytes(instances, Cc) // 4, dtype=F32, device=x.device)
+    check(lib().ccv_groupnorm_stats(_ptr(x), _kind(x, (F32, F16, BF16), "groupnorm_partial_sums"), instances, rpi, Cc, _ptr(ws), _stream()),
+          "ccv_groupnorm_stats")
+    return ws[:instances * nchunk * 64].view(instances, nchunk, 64).sum(1)
+
+
+def groupnorm_apply_sums(x, gamma, beta, sums, *, instances, total_rows_per_instance, eps, silu):
+    """The normalise half of ``groupnorm`` on given statistics: sums fp32 [instances, 64] = (sum, sum of squares) per group over ALL
+    ``total_rows_per_instance`` rows of an instance (which may live on other processes: x holds any subset of them)."""
+    _dev(x, gamma, beta, sums)
+    rows, Cc = _rows(x)
+    if rows % instances or tuple(sums.shape) != (instances, 64) or sums.dtype != F32:
+        raise CcvError("groupnorm_apply_sums: sums must be fp32 [instances, 64] and rows divisible by instances")
+    rpi = rows // instances
+    nchunk = lib().ccv_groupnorm_chunks(instances, rpi, Cc)
+    ws = torch.zeros(lib().ccv_groupnorm_ws_bytes(instances, Cc) // 4, dtype=F32, device=x.device)
+    ws[:instances * nchunk * 64].view(instances, nchunk, 64)[:, 0] = sums
+    y = torch.empty((rows, Cc), dtype=BF16, device=x.device)
+    inv_count = 1.0 / (float(total_rows_per_instance) * (Cc // 32))
+    check(lib().ccv_groupnorm_apply(_ptr(x), _kind(x, (F32, F16, BF16), "groupnorm_apply_sums"), _ptr(y), _ptr(gamma), _ptr(beta), instances, rpi, Cc,
+                                    eps, int(silu), _ptr(ws), inv_count, _stream()), "ccv_groupnorm_apply")
+    return y
+
+
 def layernorm(x, gamma, beta, *, eps=1e-5, addend=None, out2=None):
     """x [rows, C] fp32|fp16 -> bf16 (and y + addend[r % addend_rows] when addend is given; `out2`: where that second output goes)."""
     _dev(x, gamma, beta, addend)

@@ -2,12 +2,16 @@
 every clip are split evenly over the ranks of a ``torch.distributed`` group (RCCL over xGMI on a node: backend "nccl"; the CPU-side
 tests use gloo); every rank runs the UNet on its frames and the layers that mix frames exchange what they need:
 
-  * ``TemporalConvBlock`` / ``TemporalTransformer`` GroupNorm over (t, h, w): one all_reduce of the [b, 32 groups, 2] sums;
-  * ``TemporalConvBlock`` convolutions over t (kernel 3): the neighbours' edge frames (one all_gather of two frames per rank);
-  * temporal self-attention (per pixel over t) and the epipolar attention (over all t*h*w tokens): one all_gather of K | V;
+  * ``TemporalConvBlock``: per convolution ONE all_gather carrying the rank's partial GroupNorm sums [b, 32 groups, 2] AND its two
+    edge frames (un-normalised; every rank normalises the halo frames it receives with the same clip-wide statistics);
+  * ``TemporalTransformer`` GroupNorm over (t, h, w): one all_reduce of the sums;
+  * temporal self-attention (per pixel over t) and the epipolar attention (over all t*h*w tokens): the K | V of a camera block's two
+    attentions travel in one all_gather, the second temporal attention's in another;
   * the UNet output: one all_gather of the predicted noise, so that every rank runs the (tiny) DDIM update on whole clips.
+All gathers are ``all_gather_into_tensor`` into one [world, ...] buffer, issued on the compute stream.
 
-This is ~250 collectives per forward: a latency mode for ONE clip on several GPUs, not a throughput mode -- independent clips
+This is 140 collectives per forward (22 x 4 temporal convolutions + 17 norms + 16 + 17 + 1 K|V gathers + 1; round 2: ~250): the
+frame-mixing layers are sequentially dependent, so it stays a latency mode for ONE clip on several GPUs -- independent clips
 shard over GPUs with no collective at all (bench.py).  The reference has no counterpart (its only parallelism is Lightning's
 data-parallel test loop, 02_generate_videos.py:173,318).
 """
@@ -51,24 +55,57 @@ def broadcast_from_first(t, group=None):
     return t
 
 
+def _gather_into(x, world, group, state):
+    """x (same shape on every rank) -> [world, *x.shape]: ONE all_gather_into_tensor into one buffer (no per-rank list, no stack
+    copy).  Backends without the tensor form (seen: gloo on device tensors in some builds) fall back to the list form, once."""
+    x = x.contiguous()
+    if x.dim() == 0:
+        x = x.reshape(1)
+    flat = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)   # the ranks' tensors back to back
+    out = flat.view((world,) + tuple(x.shape))
+    if state.get("into_tensor", True):
+        try:
+            dist.all_gather_into_tensor(flat, x, group=group)
+            return out
+        except (RuntimeError, NotImplementedError):
+            state["into_tensor"] = False
+    dist.all_gather(list(out.unbind(0)), x, group=group)
+    return out
+
+
 class FrameShard:
     def __init__(self, group=None):
         if not dist.is_initialized():
             raise CcvError("FrameShard needs an initialised torch.distributed process group")
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.collectives = 0          # issued so far (tests assert the per-forward count)
+        self._state = {}
         _first_collective(group)
 
     def all_reduce_sum(self, t):
+        self.collectives += 1
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_gather(self, x):
-        """x (same shape on every rank) -> list of the ranks' tensors."""
-        x = x.contiguous()
-        parts = [torch.empty_like(x) for _ in range(self.world)]
-        dist.all_gather(parts, x, group=self.group)
-        return parts
+        """x (same shape on every rank) -> [world, *x.shape] (index r = rank r's tensor)."""
+        self.collectives += 1
+        return _gather_into(x, self.world, self.group, self._state)
+
+    def all_gather_packed(self, tensors):
+        """Several tensors of any dtypes in ONE collective: they travel as one byte buffer.  Returns, per input tensor, the gathered
+        [world, *shape] tensor."""
+        flat = [t.contiguous().view(torch.uint8).reshape(-1) for t in tensors]
+        sizes = [f.numel() for f in flat]
+        pad = [(-n) % 16 for n in sizes]                      # keep every part 16-byte aligned inside the buffer
+        buf = torch.cat([torch.cat([f, f.new_zeros(p)]) if p else f for f, p in zip(flat, pad)])
+        got = self.all_gather(buf)                            # [world, bytes]
+        outs, off = [], 0
+        for t, n, p in zip(tensors, sizes, pad):
+            outs.append(got[:, off:off + n].contiguous().view(t.dtype).reshape((self.world,) + tuple(t.shape)))
+            off += n + p
+        return outs
 
 
 class CfgSplit:
@@ -84,19 +121,18 @@ class CfgSplit:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world != 2:
             raise CcvError(f"the CFG split is for exactly 2 ranks (conditional / unconditional), the group has {self.world}")
+        self._state = {}
         _first_collective(group)
 
     def exchange(self, mine):
         """this rank's noise prediction -> (e_cond, e_uncond)"""
         mine = mine.contiguous()
-        # Drain the stream first.  gloo stages device tensors through the host on streams of its own, and ordered behind a hipGraph
-        # replay still in flight on the current stream its copy never started (one-GPU rehearsal of `bench.py --cfg-split`: both
-        # ranks stuck in all_gather; drained first it runs).  RCCL enqueues on the device and should not need it, but that path has not
-        # run anywhere yet; the wait costs the host's run-ahead over one ~17 ms step (the next replay needs the exchanged result anyway).
-        torch.cuda.current_stream().synchronize()
-        parts = [torch.empty_like(mine), torch.empty_like(mine)]
-        dist.all_gather(parts, mine, group=self.group)
-        return parts[0], parts[1]
+        # gloo stages device tensors through the host on streams of its own: drain the current stream first (_host_staged).  RCCL
+        # enqueues the collective on the device in stream order: no drain, the host keeps running ahead (and the step can be captured).
+        if _host_staged(self.group):
+            torch.cuda.current_stream().synchronize()
+        both = _gather_into(mine, 2, self.group, self._state)
+        return both[0], both[1]
 
 
 class FrameCtx:
@@ -118,22 +154,47 @@ class FrameCtx:
         _CUR.ctx = self._prev
 
     # ---- exchanges (rows are token-major [(b t hw), C]) ------------------------------------------------------------------
+    def _frames_first(self, parts, b, hw, C):
+        """[world, b, t_loc, hw, C] -> [(b T hw), C]; a view when b == 1 (one clip: the latency mode's case)."""
+        if b == 1:
+            return parts.reshape(self.T * hw, C)
+        return parts.permute(1, 0, 2, 3, 4).reshape(b * self.T * hw, C)
+
     def gather_frames(self, rows, b, hw):
         """this rank's rows [(b t_loc hw), C] -> all frames [(b T hw), C]."""
         C = rows.shape[-1]
-        parts = self.shard.all_gather(rows.reshape(b, self.t_loc, hw, C))
-        return torch.stack(parts, 1).reshape(b * self.T * hw, C)
+        return self._frames_first(self.shard.all_gather(rows.reshape(b, self.t_loc, hw, C)), b, hw, C)
+
+    def gather_frames_multi(self, rows_list, b, hw):
+        """Several row tensors (e.g. the K|V of a block's temporal attention and of its epipolar attention) in ONE collective."""
+        shaped = [r.reshape(b, self.t_loc, hw, r.shape[-1]) for r in rows_list]
+        return [self._frames_first(g, b, hw, g.shape[-1]) for g in self.shard.all_gather_packed(shaped)]
+
+    def halo_frames(self, parts_edges):
+        """parts_edges [world, 2, b, hw, C] (every rank's first and last local frame) -> (previous rank's last frame, next rank's
+        first frame), each [b, hw, C]; zeros at the clip's ends (the convolution's padding)."""
+        r, w = self.shard.rank, self.shard.world
+        prev = parts_edges[r - 1][1] if r > 0 else torch.zeros_like(parts_edges[0][0])
+        nxt = parts_edges[r + 1][0] if r < w - 1 else torch.zeros_like(parts_edges[0][0])
+        return prev, nxt
 
     def with_halo(self, rows, b, hw):
         """[(b t_loc hw), C] -> [(b (t_loc + 2) hw), C]: the previous rank's last frame in front and the next rank's first frame
         behind every clip's local frames (zeros at the clip's ends: the convolution's padding)."""
         C = rows.shape[-1]
         z = rows.reshape(b, self.t_loc, hw, C)
-        parts = self.shard.all_gather(torch.stack([z[:, 0], z[:, -1]], 0))          # [2, b, hw, C] per rank
-        r, w = self.shard.rank, self.shard.world
-        prev = parts[r - 1][1] if r > 0 else torch.zeros_like(z[:, 0])
-        nxt = parts[r + 1][0] if r < w - 1 else torch.zeros_like(z[:, 0])
+        prev, nxt = self.halo_frames(self.shard.all_gather(torch.stack([z[:, 0], z[:, -1]], 0)))          # [2, b, hw, C] per rank
         return torch.cat([prev[:, None], z, nxt[:, None]], 1).reshape(b * (self.t_loc + 2) * hw, C)
+
+    def edges_and_sums(self, rows, sums, b, hw):
+        """ONE collective for a temporal convolution's GroupNorm + halo: every rank's edge frames of the UN-normalised rows together
+        with its partial GroupNorm sums [b, 64].  Returns (previous rank's last frame, next rank's first frame, summed statistics,
+        is_first, is_last): the caller normalises its own rows and the two halo frames with the same clip-wide statistics."""
+        C = rows.shape[-1]
+        z = rows.reshape(b, self.t_loc, hw, C)
+        edges, all_sums = self.shard.all_gather_packed([torch.stack([z[:, 0], z[:, -1]], 0), sums])
+        prev, nxt = self.halo_frames(edges)
+        return prev, nxt, all_sums.sum(0), self.shard.rank == 0, self.shard.rank == self.shard.world - 1
 
     def inner(self, rows_ext, b, hw):
         C = rows_ext.shape[-1]

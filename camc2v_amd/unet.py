@@ -180,17 +180,23 @@ class CrossAttention(nn.Module, _Prepared):
         ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=stream, out_dtype=stream.dtype, out=stream)
 
     # ---- self attention over the frames of each pixel; activations stay token-major -------------
-    def temporal_attend(self, n, g, out=None):
-        """softmax(q k^T) v over the frames of each pixel, before the output projection: bf16 [(b t hw), C] (into `out`)."""
+    def project_qkv(self, n):
+        return ops.gemm(n, self._pk()["w_qkv"])
+
+    def temporal_attend(self, n, g, out=None, qkv=None, kv_all=None):
+        """softmax(q k^T) v over the frames of each pixel, before the output projection: bf16 [(b t hw), C] (into `out`).
+        qkv / kv_all (frame-sharded mode): this rank's projection and the K | V rows of all ranks, when the caller gathered them
+        together with another attention's (one collective for both)."""
         pk = self._pk()
         C, H, hw = self.query_dim, self.heads, g.h * g.w
-        qkv = ops.gemm(n, pk["w_qkv"])
+        if qkv is None:
+            qkv = ops.gemm(n, pk["w_qkv"])
         ld = 3 * C
         s = (g.t * hw * ld, ld, hw * ld)
         o = torch.empty((n.shape[0], C), dtype=ops.BF16, device=n.device) if out is None else out
         fc = parallel.current()
         if fc is not None:     # frames sharded over ranks: this rank's queries against every rank's keys / values
-            kv = fc.gather_frames(qkv[:, C:].contiguous(), g.b, hw)                    # [(b T hw), 2C]
+            kv = kv_all if kv_all is not None else fc.gather_frames(qkv[:, C:].contiguous(), g.b, hw)      # [(b T hw), 2C]
             sk = (fc.T * hw * 2 * C, 2 * C, hw * 2 * C)
             ops.attention(qkv, kv, kv[:, C:], B=g.b * hw, inner=hw, H=H, Lq=g.t, Lk=fc.T, q_str=s, k_str=sk, v_str=sk, out=o,
                           o_str=(g.t * hw * C, C, hw * C), scale=self.scale)
@@ -357,12 +363,17 @@ class Epipolar(nn.Module, _Prepared):
         pk = self._pk()
         ops.gemm(self.attend(src, g, packed_mask), pk["w_o"], bias=pk["b_o"], residual=stream, out_dtype=stream.dtype, out=stream)
 
-    def attend(self, src, g, packed_mask, out=None):
-        """The masked attention over all T*H*W tokens, before the output projection: bf16 [(b t hw), C] (into `out`)."""
+    def project_qkv(self, src):
+        return ops.gemm(src, self._pk()["w_qkv"])
+
+    def attend(self, src, g, packed_mask, out=None, qkv=None, kv_all=None):
+        """The masked attention over all T*H*W tokens, before the output projection: bf16 [(b t hw), C] (into `out`).
+        qkv / kv_all: see CrossAttention.temporal_attend."""
         pk = self._pk()
         C, H = self.query_dim, self.num_heads
         L = g.t * g.h * g.w
-        qkv = ops.gemm(src, pk["w_qkv"])
+        if qkv is None:
+            qkv = ops.gemm(src, pk["w_qkv"])
         ld = 3 * C
         s = (L * ld, 0, ld)
         kw = {}
@@ -375,7 +386,7 @@ class Epipolar(nn.Module, _Prepared):
             kw = dict(mask_bits=bits, tile_flags=flags, mask_nb=nb, perm=perm, wave_bits=wbits, group_order=order)
         fc = parallel.current()
         if fc is not None:     # frames sharded over ranks: local queries (and their mask rows, prepared in UNetModel.forward)
-            kv = fc.gather_frames(qkv[:, C:].contiguous(), g.b, g.h * g.w)           # against all T*h*w keys / values
+            kv = kv_all if kv_all is not None else fc.gather_frames(qkv[:, C:].contiguous(), g.b, g.h * g.w)     # against all T*h*w keys / values
             La = fc.T * g.h * g.w
             if out is not None:
                 kw.update(out=out, o_str=(L * C, 0, C))
@@ -457,8 +468,16 @@ class BasicTransformerBlock(nn.Module, _Prepared):
                 rows, C = stream.shape
                 stack = torch.empty((3, rows, C), dtype=ops.BF16, device=stream.device)   # [o1 ; n + P ; o2]
                 n, _ = self._ln(1, stream, addend=prow, out2=stack[1])
-                self.attn1.temporal_attend(n, g, out=stack[0])
-                self.epipolar.attend(stack[1], g, cam.get("mask"), out=stack[2])
+                fc = parallel.current()
+                if fc is not None:     # frames sharded over ranks: the K | V of both attentions in ONE all_gather
+                    Cq = self.attn1.query_dim
+                    qkv1, qkv2 = self.attn1.project_qkv(n), self.epipolar.project_qkv(stack[1])
+                    kv1, kv2 = fc.gather_frames_multi([qkv1[:, Cq:].contiguous(), qkv2[:, Cq:].contiguous()], g.b, g.h * g.w)
+                    self.attn1.temporal_attend(n, g, out=stack[0], qkv=qkv1, kv_all=kv1)
+                    self.epipolar.attend(stack[1], g, cam.get("mask"), out=stack[2], qkv=qkv2, kv_all=kv2)
+                else:
+                    self.attn1.temporal_attend(n, g, out=stack[0])
+                    self.epipolar.attend(stack[1], g, cam.get("mask"), out=stack[2])
                 ops.gemm(stack.view(3 * rows, C), pk["w_cam"], k=C, taps=3, m=rows, gather=ops.GATHER_SEGMENTS, seg_rows=rows,
                          bias=pk["b_cam"], residual=stream, out_dtype=stream.dtype, out=stream)
                 self.attn2.self_attn_temporal(self._ln(2, stream), stream, g)
@@ -642,11 +661,23 @@ class TemporalConvBlock(nn.Module, _Prepared):
             if fc is None:    # (h carries the statistics its producing convolution emitted: whole clip = one instance)
                 z = ops.groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], instances=g.b, eps=1e-5, silu=True)
             else:
-                z = _clip_groupnorm(h, pk[f"g{i}"], pk[f"b{i}"], g, 1e-5, True)
+                # frames sharded over ranks: ONE collective per convolution -- every rank's partial GroupNorm sums travel with its
+                # two (un-normalised) edge frames; the clip-wide statistics then normalise the local rows and the two halo frames alike
+                hw = g.h * g.w
+                total = fc.T * hw
+                prev, nxt, sums, first, lastr = fc.edges_and_sums(h, ops.groupnorm_partial_sums(h, g.b), g.b, hw)
+                norm = lambda rows: ops.groupnorm_apply_sums(rows, pk[f"g{i}"], pk[f"b{i}"], sums, instances=g.b,
+                                                             total_rows_per_instance=total, eps=1e-5, silu=True)
+                z = norm(h)
+                halo = norm(torch.stack([prev, nxt], 1).reshape(g.b * 2 * hw, C)).reshape(g.b, 2, hw, C)
+                if first:
+                    halo[:, 0].zero_()        # the clip's ends: the convolution's zero padding (not normalised zeros)
+                if lastr:
+                    halo[:, 1].zero_()
+                ze = torch.cat([halo[:, :1], z.reshape(g.b, g.t, hw, C), halo[:, 1:]], 1).reshape(g.b * (g.t + 2) * hw, C)
             last = i == 3
             if fc is not None:     # frames sharded over ranks: the neighbours' edge frames in front of / behind the local ones
                 hw = g.h * g.w
-                ze = fc.with_halo(z, g.b, hw)
                 he = ops.gemm(ze, pk[f"w{i}"], k=C, taps=3, bias=pk[f"cb{i}"], gather=ops.GATHER_TCONV3, tconv=(g.t + 2, hw),
                               out_dtype=torch.float32 if last else ops.BF16)
                 h = fc.inner(he, g.b, hw)
@@ -1056,8 +1087,9 @@ class UNetModel(nn.Module, _Prepared):
         return dict(rows=rows, masks=masks, add_type=cam["add_type"])
 
     def enable_frame_sharding(self, group=None):
-        """Shard the frames of every clip over the ranks of ``group`` (default: the world); see parallel.py.  hipGraph capture of
-        the sampling step is not available in this mode (the exchanges are torch.distributed calls)."""
+        """Shard the frames of every clip over the ranks of ``group`` (default: the world); see parallel.py.  The exchanges are
+        torch.distributed calls on the compute stream: under RCCL ("nccl") the sampling step can be captured into a hipGraph
+        (bench.py --frame-shard --shard-graph), under gloo (tests) it runs eagerly."""
         self.__dict__["frame_shard"] = parallel.FrameShard(group)
         return self
 
@@ -1088,7 +1120,7 @@ class UNetModel(nn.Module, _Prepared):
             with parallel.FrameCtx(shard, x.shape[2]) as fc:
                 xl = x[:, :, fc.f0:fc.f0 + fc.t_loc].contiguous()
                 yl = self.forward(xl, timesteps, context, None, fs, camera_condition, cfg_shared_input, **kwargs)
-                return torch.cat(shard.all_gather(yl), 2)
+                return torch.cat(list(shard.all_gather(yl).unbind(0)), 2)
         if not ops.in_queue_counter_arena():   # one zeroed buffer for the queue counters of this forward's sparse attentions (per thread)
             with ops.queue_counter_arena(x.device):
                 return self.forward(x, timesteps, context, None, fs, camera_condition, cfg_shared_input, **kwargs)

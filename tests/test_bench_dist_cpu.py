@@ -70,6 +70,22 @@ def test_two_rank_bench_main(tmp_path):
                          "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
+def test_eight_rank_bench_main(tmp_path):
+    """The driver's N = 8 launch shape on CPU: eight gloo ranks, one clip stream each (no collective inside the loop), the final
+    all_gather sees eight distinct latents, the job time is the slowest rank's, and the line lists every rank's own time."""
+    world, port = 8, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), 1, 2), nprocs=world, join=True)
+    r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(world)]
+    assert all(x["rc"] == 0 for x in r) and all(x["clips"] == [0, 1, 2, 3] for x in r)
+    assert all(x["stdout"].strip() == "" for x in r[1:])
+    line = json.loads([ln for ln in r[0]["stdout"].splitlines() if ln.strip()][0])
+    assert line["n_gpus"] == 8 and line["config"]["ranks_in_final_all_gather"] == 8 and line["config"]["parallelism"] == "clip-dp8"
+    per = line["config"]["per_rank_ms_per_step"]
+    assert len(per) == 8 and max(per) <= line["ms_per_step"] + 1e-6        # (the job time adds the closing all_gather + barriers of 8 gloo processes)
+    assert per[7] >= per[0] + 200.0                    # rank r sleeps 0.05 (1 + r) s per clip: the slow rank sets the job time
+    assert line["value"] == pytest.approx(16.0 * 2 * 8 / (line["ms_per_step"] * 2 / 1e3))
+
+
 def test_two_rank_bench_main_with_two_clips_in_flight(tmp_path):
     """--lanes 2: every lane runs the W warm-up clips itself (its graphs are captured there), then the lanes share exactly K
     timed clips (each sampled once, by whichever lane is free) and overlap them in time."""
