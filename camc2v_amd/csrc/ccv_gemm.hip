@@ -1445,7 +1445,12 @@ __device__ __forceinline__ void wait_vm_only() {
 
 enum { AS_BF16_WIDE = 0, AS_BF16 = 1, AS_F32 = 2, AS_GEGLU = 3, AS_F16 = 4 };   // AS_F16: fp16 output (16-byte pair stores), fp16 residual
 
-template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
+// LNF (round 3): the activation operand is the fp16 residual stream itself and the LayerNorm in front of the projection
+// (attention.py:248-253: norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff) runs HERE, on the whole K = 320 rows the
+// workgroup stages anyway: statistics over the row (two passes over the LDS tile: mean, then centred sum of squares, folded over the
+// four lanes that share a row), then (x - mean) rstd gamma + beta rounded to bf16 straight into the fragment registers.  No
+// LayerNorm launch, no normalised copy of the stream in memory.
+template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     // 8 waves = 4 (rows) x 2 (columns), wave tile 32 rows x 32 columns, two waves per SIMD.  Measured on the way here
     // (profiles/r02_astat_notes.txt): 4 waves of 64 rows, one per SIMD, add the phases up (knock-out: MFMA 9.6 us + stores 7.8 us
@@ -1513,14 +1518,56 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     asm volatile("s_barrier" ::: "memory");
     // ---- this wave's activation fragments: rows 32 wm + 16 i + fr of the tile, k = 32 ks + 8 fg .. + 7 -----------------
     bf16x8 fa[KS][MT];
-    static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
-        constexpr int ks = decltype(Q)::value;
-        constexpr int slab = ks >> 1;
-        const int c = (ks & 1) * 4 + fg;
+    if constexpr (LNF) {
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+        auto frag = [&](int ks, int i) {       // 8 consecutive k of row 32 wm + 16 i + fr, as stored (fp16)
+            const int slab = ks >> 1, c = (ks & 1) * 4 + fg;
+            return *reinterpret_cast<const f16x8*>(smem + slab * BM * 128 + lds_off<64>(wm * 16 * MT + 16 * i + fr, c));
+        };
+        auto row_sum = [](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };   // the 4 lanes (fg) of a row
+        float mean[MT], rstd[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-            fa[ks][i] = *reinterpret_cast<const bf16x8*>(smem + slab * BM * 128 + lds_off<64>(wm * 16 * MT + 16 * i + fr, c));
-    });
+        for (int i = 0; i < MT; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 h = frag(ks, i);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += (float)h[e];
+            }
+            mean[i] = row_sum(a) * (1.0f / (float)K);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 h = frag(ks, i);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)h[e] - mean[i]; q += d * d; }
+            }
+            rstd[i] = rsqrtf(row_sum(q) * (1.0f / (float)K) + p.ln_eps);
+        }
+        static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            const int k0 = 32 * ks + 8 * fg;
+            const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + k0), g1 = *reinterpret_cast<const float4*>(p.ln_gamma + k0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.ln_beta + k0), b1 = *reinterpret_cast<const float4*>(p.ln_beta + k0 + 4);
+            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const f16x8 h = frag(ks, i);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fa[ks][i][e] = (__bf16)(((float)h[e] - mean[i]) * rstd[i] * gm[e] + bt[e]);
+            }
+        });
+    } else {
+        static_for<0, KS, 1>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            constexpr int slab = ks >> 1;
+            const int c = (ks & 1) * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[ks][i] = *reinterpret_cast<const bf16x8*>(smem + slab * BM * 128 + lds_off<64>(wm * 16 * MT + 16 * i + fr, c));
+        });
+    }
     // retire the fragment reads (an lgkmcnt(0) where hipcc can see it), then every wave is done with stages 0 / 1
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -1661,10 +1708,10 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     wait_vm_only<0>();   // the zero-line pieces issued past the last strip target this workgroup's LDS: retire them before it is released
 }
 
-template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES>
+template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES, bool LNF = false>
 int launch_astat(const CcvGemm& p, hipStream_t st) {
     constexpr size_t lds = 3 * (size_t)NSLAB * 64 * 128;
-    auto kern = gemm_astat_kernel<NSLAB, MODE, HAS_BIAS, HAS_RES>;
+    auto kern = gemm_astat_kernel<NSLAB, MODE, HAS_BIAS, HAS_RES, LNF>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1681,6 +1728,9 @@ constexpr int ASTAT_TILE = -4;   // ccv_gemm_plan's *tile code for it
 inline bool astat_fits(const CcvGemm& p) {
     static const bool on = [] { const char* e = getenv("CCV_GEMM_ASTAT"); return !(e && e[0] == '0'); }();   // A/B aid
     if (!on || tune_env("CCV_GEMM_RING") != -2 || tune_env("CCV_GEMM_FAMTILE") != -2 || tune_env("CCV_GEMM_SPLIT") > 0) return false;
+    if (p.ln_gamma != nullptr &&      // LayerNorm prologue: instantiated for the projections that follow a LayerNorm (QKV / q: bf16 out, no bias; GEGLU)
+        !(p.ln_beta != nullptr && p.residual == nullptr && (p.geglu ? p.bias != nullptr : (p.out_f32 == 0 && p.bias == nullptr && (p.ldc & 7) == 0))))
+        return false;
     return p.gather == 0 && p.taps == 1 && !p.a_f32 && p.K == 320 && p.M % 128 == 0 && p.M / 128 >= 192 && p.M / 128 <= 512 &&
            p.N % 64 == 0 && p.N >= 128 && p.act == 0 && p.bias2 == nullptr && (p.out_f32 || p.residual == nullptr) &&
            (p.residual == nullptr || (p.res_f16 != 0) == (p.out_f32 == 2)) && (p.out_f32 != 2 || (p.ldc & 7) == 0) &&
@@ -1695,6 +1745,10 @@ int dispatch_astat_mode(const CcvGemm& p, hipStream_t st) {
     return p.bias ? launch_astat<5, MODE, true, false>(p, st) : launch_astat<5, MODE, false, false>(p, st);
 }
 inline int dispatch_astat(const CcvGemm& p, hipStream_t st) {
+    if (p.ln_gamma) {      // (astat_fits admitted only these two flavours)
+        if (p.geglu) return launch_astat<5, AS_GEGLU, true, false, true>(p, st);
+        return launch_astat<5, AS_BF16_WIDE, false, false, true>(p, st);
+    }
     if (p.geglu) return dispatch_astat_mode<AS_GEGLU>(p, st);
     if (p.out_f32 == 2) return dispatch_astat_mode<AS_F16>(p, st);
     if (p.out_f32) return dispatch_astat_mode<AS_F32>(p, st);
@@ -1737,6 +1791,10 @@ extern "C" int64_t ccv_gemm_ws_bytes(const CcvGemm* pp) {
     if (astat_fits(*pp)) return 0;
     const Plan pl = make_plan(*pp, true);
     return pl.split > 1 ? (int64_t)pl.split * pp->M * pp->N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t ccv_gemm_ln_fusable(const CcvGemm* pp) {
+    return (pp != nullptr && pp->ln_gamma != nullptr && plan_ok(*pp) && astat_fits(*pp)) ? 1 : 0;
 }
 
 extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
@@ -1823,6 +1881,8 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
                                   (ccv_gemm_ws_bytes(&p) == 0 || p.split_k > 1)), CCV_EINVAL,
                 "ccv_gemm: gn_partial needs gn_rows and gn_slots = ccv_gemm_gn_slots() > 0 for this problem (got rows %d, slots %d)", p.gn_rows, p.gn_slots);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    CCV_REQUIRE(p.ln_gamma == nullptr || (plan_ok(p) && astat_fits(p)), CCV_ESHAPE,
+                "ccv_gemm: the LayerNorm prologue (ln_gamma) exists in the A-stationary kernel only: ask ccv_gemm_ln_fusable() first");
     if (plan_ok(p) && astat_fits(p)) return dispatch_astat(p, st);
     switch (p.gather) {
         case 0:

@@ -25,6 +25,7 @@ class CcvGemm(C.Structure):
         ("ws", vp), ("ws_bytes", i64), ("split_k", i32),
         ("gn_partial", vp), ("gn_rows", i32), ("gn_slots", i32),
         ("res_f16", i32), ("tile_order", i32),
+        ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
     ]
 
 
@@ -60,6 +61,7 @@ SIGNATURES = {
     "ccv_gemm": (i32, [C.POINTER(CcvGemm), vp]),
     "ccv_gemm_ws_bytes": (i64, [C.POINTER(CcvGemm)]),
     "ccv_gemm_plan": (i32, [C.POINTER(CcvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ccv_gemm_ln_fusable": (i32, [C.POINTER(CcvGemm)]),
     "ccv_gemm_gn_slots": (i32, [C.POINTER(CcvGemm), i32]),
     "ccv_groupnorm_apply_parts": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),

@@ -54,9 +54,41 @@ def _rows(t):
 # ---------------------------------------------------------------------------------------
 # GEMM family
 # ---------------------------------------------------------------------------------------
+STREAMS_IN_FLIGHT = 1
+
+
 def set_streams_in_flight(n):
     """Planner hint: how many independent launch streams the caller keeps busy (see include/ccv.h).  Returns the previous value."""
+    global STREAMS_IN_FLIGHT
+    STREAMS_IN_FLIGHT = max(1, int(n))
     return lib().ccv_set_streams_in_flight(int(n))
+
+
+# LayerNorm in the consuming GEMM's prologue: "1" always, "0" never, default "auto" = when ONE launch stream is busy.  Measured in the
+# model on one box (profiles/r03_ab_switches.txt): one clip at a time +0.8 % (25 launches and 1 GB of traffic per step less); with two
+# clips in flight -1.1 % -- the separate LayerNorm is a streaming kernel that runs beside the other clip's GEMMs for free, while the
+# longer prologue holds a whole CU's LDS.
+_FUSE_LN_MODE = __import__("os").environ.get("CCV_LN_FUSE", "auto")
+
+
+def _fuse_ln():
+    return _FUSE_LN_MODE == "1" or (_FUSE_LN_MODE != "0" and STREAMS_IN_FLIGHT < 2)
+
+
+class LazyLN:
+    """LayerNorm(x) as a GEMM operand that need not exist in memory: ``gemm(LazyLN(...), w)`` runs the norm inside the GEMM's prologue
+    where the kernel for that problem has one (ccv_gemm_ln_fusable: the A-stationary kernel of the 32x32-latent blocks, x the fp16
+    stream) and otherwise materialises the bf16 rows with ``layernorm`` first (once: the result is kept for further consumers)."""
+
+    def __init__(self, x, gamma, beta, eps):
+        self.x, self.gamma, self.beta, self.eps = x, gamma, beta, float(eps)
+        self.shape, self.device, self.dtype = x.shape, x.device, BF16
+        self._t = None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = layernorm(self.x, self.gamma, self.beta, eps=self.eps)
+        return self._t
 
 
 def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2=None, ldb2=0, rows_per_batch=0,
@@ -74,6 +106,10 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw);
     seg_rows (GATHER_SEGMENTS): a = `taps` stacked operands, `seg_rows` rows apart; tap t multiplies rows [t*seg_rows, +M).
     """
+    ln = None
+    if isinstance(a, LazyLN):       # try the LayerNorm prologue (decided below, once the problem is described); else the norm runs first
+        ln = a
+        a = ln.x if (_fuse_ln() and ln._t is None and ln.x.dtype == F16 and gather == GATHER_LINEAR and taps == 1) else ln.tensor()
     _dev(a, w, bias, bias2, residual, out)
     if a.dim() != 2 or a.stride(1) != 1:
         raise CcvError("gemm: A must be 2-D with a contiguous last dim")
@@ -101,7 +137,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     p.ldb2 = ldb2 if bias2 is not None else 0
     if a.dtype == F32:
         p.a_f32 = 1
-    elif a.dtype == BF16:
+    elif a.dtype == BF16 or (ln is not None and a is ln.x):      # (the fp16 stream under a LayerNorm prologue: two bytes per element too)
         p.a_f32 = 0
     else:
         raise CcvError(f"gemm: unsupported A dtype {a.dtype}")
@@ -150,6 +186,11 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
             raise CcvError(f"gemm: bias2 must hold {nb2} fp32 rows of >= {N} columns, ldb2 = {ldb2} apart")
     p.rows_per_batch = rows_per_batch
     p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), {BF16: 0, F32: 1, F16: 2}[out_dtype], alpha
+    if ln is not None and a is ln.x:
+        p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(ln.gamma), _ptr(ln.beta), ln.eps
+        if not lib().ccv_gemm_ln_fusable(C.byref(p)):          # no prologue for this problem: normalise first
+            a = ln.tensor()
+            p.A, p.lda, p.ln_gamma, p.ln_beta = _ptr(a), (lda if lda is not None else a.stride(0)), None, None
     stats = None
     if gn_rows and M % gn_rows == 0 and not lib().ccv_groupnorm_single_launch(M // gn_rows, gn_rows, n_cols, _KIND[out_dtype]):
         slots = lib().ccv_gemm_gn_slots(C.byref(p), gn_rows)

@@ -447,7 +447,11 @@ class BasicTransformerBlock(nn.Module, _Prepared):
         return pk
 
     def _ln(self, i, stream, addend=None, out2=None):
+        """LayerNorm i of the stream: with an addend (the Pluecker rows) the two bf16 tensors, else a lazy operand -- the projection
+        that consumes it runs the norm in its own prologue where its kernel can (ops.LazyLN)."""
         pk = self._pk()
+        if addend is None and out2 is None:
+            return ops.LazyLN(stream, pk[f"g{i}"], pk[f"b{i}"], getattr(self, f"norm{i}").eps)
         return ops.layernorm(stream, pk[f"g{i}"], pk[f"b{i}"], eps=getattr(self, f"norm{i}").eps, addend=addend, out2=out2)
 
     def run_spatial(self, stream, g, ctx_groups, final=False):
@@ -485,7 +489,7 @@ class BasicTransformerBlock(nn.Module, _Prepared):
             if prow is not None:
                 n, src = self._ln(1, stream, addend=prow)
             else:
-                n = src = self._ln(1, stream)
+                n = src = self._ln(1, stream).tensor()     # several consumers, the stream changes between them: materialise
             target = stream if main else torch.zeros_like(stream)
             if main:
                 self.attn1.self_attn_temporal(n, stream, g)

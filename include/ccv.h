@@ -116,6 +116,13 @@ typedef struct CcvGemm {
     int32_t res_f16;        /* 0: residual is fp32, 1: residual is fp16 (the residual stream's hand-off format between blocks:
                              * what the reference carries under torch.autocast, main/trainer.py:193; arithmetic stays fp32) */
     int32_t tile_order;     /* set by the library; callers leave it 0 (0: an XCD walks output tiles N-fastest, 1: M-fastest) */
+    /* LayerNorm prologue: NULL, or gamma / beta [K] fp32 of the LayerNorm in front of this projection (attention.py:248-253): A is then
+     * the fp16 residual stream [M, lda] itself and every row is normalised over its K = C channels (fp32 statistics, eps = ln_eps)
+     * on its way into the MFMA operand registers.  Only problems ccv_gemm_ln_fusable() admits (the A-stationary kernel: K = 320, the
+     * 32x32-latent blocks; bf16 output without bias, or the GEGLU up-projection); for the rest run ccv_layernorm first. */
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_eps;
 } CcvGemm;
 /* Workspace the library would like for this problem (0 = none).  Long-K, few-tile problems (the 4x4 and 8x8
  * latent layers) are split along K over extra workgroups when the workspace is provided; without it the
@@ -130,6 +137,8 @@ int ccv_gemm(const CcvGemm* p, void* stream);
  * 24576 .. 65536 rows: one workgroup per CU keeps its 128 activation rows in registers, weights stream in 64-column strips);
  * *split = split-K factor. */
 int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
+/* 1 when ccv_gemm can run this problem with its LayerNorm prologue (p->ln_gamma set), 0 when the caller must normalise first. */
+int32_t ccv_gemm_ln_fusable(const CcvGemm* p);
 /* Slots per instance the epilogue statistics of this problem would take (see gn_partial), 0 when the kernel ccv_gemm would run
  * cannot produce them (GEGLU / activation epilogues, fp32 activations, the A-stationary kernel, tiles without a statistics
  * instance, tile rows not dividing the instance, more than 512 slots): the caller then runs ccv_groupnorm as usual. */

@@ -1019,3 +1019,43 @@ def test_groupnorm_statistics_from_stream_epilogues(ops, case):
     d = (y.float() - y0.float()).abs()
     assert d.max().item() <= 2.0 ** -6 * max(1.0, y0.float().abs().max().item()), d.max().item()
     assert (d > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("N,geglu", [(960, False), (320, False), (2560, True)])
+def test_gemm_with_layernorm_prologue(ops, N, geglu):
+    """LayerNorm folded into the A-stationary kernel's prologue (K = 320, the fp16 stream as the operand): against LayerNorm -> bf16 ->
+    GEMM through the separate kernels (same arithmetic up to the order of the row reductions) and against torch fp32."""
+    from camc2v_amd.pack import interleave_geglu
+    M, K = 32768, 320
+    x = (rnd(M, K, seed=80, dtype=torch.float32) * 1.5 + 0.4).to(torch.float16)
+    gamma, beta = 1.0 + rnd(K, seed=81, dtype=torch.float32) * 0.2, rnd(K, seed=82, dtype=torch.float32) * 0.1
+    w = rnd(N, K, seed=83, scale=0.05)
+    bias = rnd(N, seed=84, dtype=torch.float32) if geglu else None
+    kw = {}
+    if geglu:
+        w, bias = interleave_geglu(w, bias)
+        kw = dict(bias=bias, geglu=True)
+    ops.TRACK_GEMM_PLAN = True
+    try:
+        got = ops.gemm(ops.LazyLN(x, gamma, beta, 1e-5), w, **kw)
+        plan = ops.LAST_GEMM_PLAN
+    finally:
+        ops.TRACK_GEMM_PLAN = False
+    assert plan[0] == -4, f"expected the A-stationary kernel, plan {plan}"
+    n = ops.layernorm(x, gamma, beta, eps=1e-5)
+    sep = ops.gemm(n, w, **kw)
+    d = (got.float() - sep.float()).abs()
+    assert d.max().item() <= 2.0 ** -5 * max(1.0, sep.float().abs().max().item()), d.max().item()     # bf16 rounding steps of n and of the output
+    assert (d > 0).float().mean().item() < 0.2
+    nf = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5).to(torch.bfloat16).float()
+    # reference with the same operand rounding (bf16 LayerNorm output), fp32 accumulate
+    wf = w.float()
+    full = nf @ wf.t() + (bias if bias is not None else 0.0)
+    if geglu:      # interleaved 16-row value / gate blocks
+        blocks = full.reshape(M, N // 32, 2, 16)
+        full = (blocks[:, :, 0] * F.gelu(blocks[:, :, 1])).reshape(M, N // 2)
+    assert_close(got, full, 1.5e-2, "LayerNorm prologue vs torch")
+    # a shape without the prologue falls back to LayerNorm + GEMM transparently
+    x2 = x[:4096]
+    fb = ops.gemm(ops.LazyLN(x2, gamma, beta, 1e-5), w, **kw)
+    assert torch.equal(fb, ops.gemm(ops.layernorm(x2, gamma, beta, eps=1e-5), w, **kw))
