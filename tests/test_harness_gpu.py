@@ -86,12 +86,13 @@ def test_generate_small_model_from_checkpoint_matches_log_images(tmp_path):
     torch.save({"state_dict": sd, "global_step": 50000}, tmp_path / "small.ckpt")
     batch = collate([SyntheticRealEstate(num_samples=1, resolution=[64, 64], num_additional_cond_frames=2)[0]])
     kw = cfg["lightning"]["callbacks"]["batch_logger"]["params"]["log_images_kwargs"]
-    torch.manual_seed(11)
-    logs = model.log_images(copy.deepcopy(batch), split="test", use_graph=True, **kw)
+    from camc2v_amd import rng
+    with rng.seeded(20230211 * 1000003 + 0, dev):       # the harness's generator for dataset index 0 (harness.generate, --seed default)
+        logs = model.log_images(copy.deepcopy(batch), split="test", use_graph=True, **kw)
     assert set(logs) >= {"samples", "gt_video", "image_condition", "reconst", "condition", "camera_data", "video_path", "cond_frames", "depth_scale"}
     assert logs["samples"].shape == (1, 3, 16, 64, 64) and torch.isfinite(logs["samples"]).all()
     del model
-    torch.manual_seed(11)
+    torch.manual_seed(11)                                # must not matter: the harness seeds every batch itself
     written = harness.generate(cfg, device=dev)
     assert [os.path.basename(w) for w in written] == ["synthetic_00000"] and sorted(os.listdir(written[0])) == FILES
     try:
