@@ -3,6 +3,7 @@
 rotate through > 256 MB of copies, as inside the model): every family tile x LDS stages x split-K, every ring tile x split-K,
 against what the built-in planner picks.  Feeds the per-shape table of csrc/ccv_gemm.hip (plan_override).
     CCV_GEMM_TUNE=1 python tools/plan_sweep.py [min_gain_percent]
+    CCV_SWEEP_AUTO_ONLY=1 [CCV_HIP_LIB=other/libccv_hip.so] python tools/plan_sweep.py      # the planner's choices only (A/B of two builds)
 """
 import os
 import sys
@@ -116,6 +117,10 @@ def main():
         ref = out.float().clone()
         auto_plan = ops.LAST_GEMM_PLAN
         t_auto = timed_graph(fn)
+        if os.environ.get("CCV_SWEEP_AUTO_ONLY"):            # A/B of two builds of the library: the planner's choice only
+            total_auto += t_auto * count
+            print(f"{kind:5s} M={M:6d} N={N:6d} K={K:5d} {flavour:6s} x{count:2d} auto {auto_plan} {t_auto:6.1f} us ({flops / t_auto / 1e6:5.0f} TF/s)", flush=True)
+            continue
         res = []
         cands = [dict(CCV_GEMM_RING=-1, CCV_GEMM_FAMTILE=ft, CCV_GEMM_ST=st, CCV_GEMM_SPLIT=sp)
                  for ft in (44, 24, 42, 22, 45, 25) for st in (2, 3) for sp in (1, 2, 3, 4, 8)]
@@ -150,6 +155,9 @@ def main():
         flag = "  <== " if gain >= min_gain else ""
         print(f"{kind:5s} M={M:6d} N={N:6d} K={K:5d} {flavour:6s} x{count:2d} auto {auto_plan} {t_auto:6.1f} us ({flops / t_auto / 1e6:5.0f} TF/s) | best {best_k} {best_t:6.1f} us "
               f"({gain:+.0f} %){flag} | {top}", flush=True)
+    if os.environ.get("CCV_SWEEP_AUTO_ONLY"):
+        print(f"# sum over the forward: planner {total_auto / 1e3:.2f} ms")
+        return
     print(f"# sum over the forward: planner {total_auto / 1e3:.2f} ms, per-shape best {total_best / 1e3:.2f} ms ({100 * (1 - total_best / total_auto):.1f} % less)")
 
 
