@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 SEED = 20230211          # reference default seed (main/trainer.py:21)
 N_CONTEXT = 2            # extra context frames -> cond context 77 + 256*(1+N) tokens
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # PMC-derived bytes of this round's profile run
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # PMC-derived bytes of this round's profile run
 
 
 def build_model(device, unet_params=None):

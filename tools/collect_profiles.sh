@@ -14,7 +14,7 @@ trace() {            # name, bench flags...
     local name=$1; shift
     rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_$name -- python3 bench.py "$@" > "$out/$name.log" 2>&1
     python3 tools/summarize_rocprof.py /tmp/rp_$name "$out/${tag}_rocprofv3_kernel_stats_$name.txt" --gaps --delete > /dev/null
-    tail -n 1 "$out/$name.log" > "$out/${tag}_bench_under_rocprof_$name.json"
+    grep -h "^{" "$out/$name.log" | tail -n 1 > "$out/${tag}_bench_under_rocprof_$name.json"
     echo "done $name"
 }
 pmc() {              # name, counters...
