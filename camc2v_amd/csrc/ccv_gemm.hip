@@ -1725,6 +1725,94 @@ int launch_astat(const CcvGemm& p, hipStream_t st) {
 // The A-stationary kernel takes the problem when one 128-row workgroup per CU covers M with at most a quarter of the chip idle,
 // K fits the register-resident activation tile and nothing but a plain linear map is asked for.
 constexpr int ASTAT_TILE = -4;   // ccv_gemm_plan's *tile code for it
+
+// -------------------------------------------------------------------------------------------------
+// Row-vector kernel: M <= 4 rows (one per sample: the timestep / frame-stride MLPs and the projection of their sum onto all 22
+// ResBlocks' embedding inputs, openaimodel3d.py:583-592,140-152 -- five launches per forward).  A 128-row MFMA tile spends 25-33 us
+// per launch walking K serially for one useful row; the work is a matrix-vector product bound by reading W once.  One wave per 4
+// output columns, lane l takes the 16-byte chunks l, l + 64, ... of the K axis of those 4 weight rows, fp32 partial sums are folded
+// across the wave in a fixed order and lanes 0 .. M-1 run the ordinary epilogue for their row.
+// -------------------------------------------------------------------------------------------------
+constexpr int SKINNY_TILE = -5;   // ccv_gemm_plan's *tile code for it
+inline bool skinny_fits(const CcvGemm& p) {
+    static const bool on = [] { const char* e = getenv("CCV_GEMM_SKINNY"); return !(e && e[0] == '0'); }();   // A/B aid
+    return on && p.M <= 4 && p.gather == 0 && p.taps == 1 && !p.geglu && p.gn_partial == nullptr && p.ln_gamma == nullptr && p.N % 4 == 0 && p.K % 8 == 0;
+}
+
+template <bool A_F32>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const CcvGemm p) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = 4 * (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+    if (n0 >= p.N) return;
+    float acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+    const int chunks = p.K >> 3;
+    for (int c = lane; c < chunks; c += 64) {
+        float a[4][8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m < p.M) {
+                if (A_F32) {
+                    const float4* ap = reinterpret_cast<const float4*>(static_cast<const float*>(p.A) + (long)m * p.lda + 8 * c);
+                    const float4 lo = ap[0], hi = ap[1];
+                    const float raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[m][q] = bf16_to_f32(f32_to_bf16(raw[q]));   // "converted on load" like the tiled kernels
+                } else {
+                    const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.A) + (long)m * p.lda + 8 * c);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[m][2 * q] = __uint_as_float(w[q] << 16);
+                        a[m][2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[m][q] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p.W + (long)(n0 + j) * p.K + 8 * c);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            float wf[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wf[2 * q] = __uint_as_float(w[q] << 16);
+                wf[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[m][j] = fmaf(a[m][q], wf[q], acc[m][j]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[m][j] += __shfl_xor(acc[m][j], off, 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (lane == m && m < p.M) {
+            float o[4] = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
+            epilogue_store(p, m, n0, o);
+        }
+}
+
+static int dispatch_skinny(const CcvGemm& p, hipStream_t st) {
+    const unsigned waves = (unsigned)(p.N / 4);
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (p.a_f32) hipLaunchKernelGGL(gemm_skinny_kernel<true>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<false>, grid, block, 0, st, p);
+    CCV_LAUNCH_CHECK("ccv_gemm(row vector)");
+    return CCV_OK;
+}
 inline bool astat_fits(const CcvGemm& p) {
     static const bool on = [] { const char* e = getenv("CCV_GEMM_ASTAT"); return !(e && e[0] == '0'); }();   // A/B aid
     if (!on || tune_env("CCV_GEMM_RING") != -2 || tune_env("CCV_GEMM_FAMTILE") != -2 || tune_env("CCV_GEMM_SPLIT") > 0) return false;
@@ -1788,7 +1876,7 @@ extern "C" int ccv_set_streams_in_flight(int32_t n) {
 
 extern "C" int64_t ccv_gemm_ws_bytes(const CcvGemm* pp) {
     if (pp == nullptr || !plan_ok(*pp)) return 0;
-    if (astat_fits(*pp)) return 0;
+    if (astat_fits(*pp) || skinny_fits(*pp)) return 0;
     const Plan pl = make_plan(*pp, true);
     return pl.split > 1 ? (int64_t)pl.split * pp->M * pp->N * (int64_t)sizeof(float) : 0;
 }
@@ -1800,6 +1888,11 @@ extern "C" int32_t ccv_gemm_ln_fusable(const CcvGemm* pp) {
 extern "C" int ccv_gemm_plan(const CcvGemm* pp, int32_t* tile, int32_t* split) {
     CCV_REQUIRE(pp && tile && split, CCV_EINVAL, "ccv_gemm_plan: null pointer");
     CCV_REQUIRE(plan_ok(*pp), CCV_ESHAPE, "ccv_gemm_plan: bad problem sizes");
+    if (skinny_fits(*pp)) {
+        *tile = SKINNY_TILE;
+        *split = 1;
+        return CCV_OK;
+    }
     if (astat_fits(*pp)) {
         *tile = ASTAT_TILE;
         *split = 1;
@@ -1831,7 +1924,7 @@ static bool gn_tile_dims(const CcvGemm& p, const Plan& pl, int& bm, int& bn) {
 extern "C" int32_t ccv_gemm_gn_slots(const CcvGemm* pp, int32_t rows_per_instance) {
     if (pp == nullptr || rows_per_instance <= 0) return 0;
     const CcvGemm& p = *pp;
-    if (!plan_ok(p) || astat_fits(p) || p.a_f32 || p.geglu || p.act != 0) return 0;
+    if (!plan_ok(p) || astat_fits(p) || skinny_fits(p) || p.a_f32 || p.geglu || p.act != 0) return 0;
     if (p.N % 64 != 0 || p.M % rows_per_instance != 0) return 0;
     const Plan pl = make_plan(p, true);
     if (pl.split > 1) {      // the reduce kernel emits them: one slot per RB rows of an instance
@@ -1884,6 +1977,10 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(p.ln_gamma == nullptr || (plan_ok(p) && astat_fits(p)), CCV_ESHAPE,
                 "ccv_gemm: the LayerNorm prologue (ln_gamma) exists in the A-stationary kernel only: ask ccv_gemm_ln_fusable() first");
     if (plan_ok(p) && astat_fits(p)) return dispatch_astat(p, st);
+    if (skinny_fits(p)) {
+        p.split_k = 1;
+        return dispatch_skinny(p, st);
+    }
     switch (p.gather) {
         case 0:
             CCV_REQUIRE(p.taps == 1, CCV_EINVAL, "ccv_gemm: linear gather needs taps == 1");

@@ -135,6 +135,8 @@ int ccv_gemm(const CcvGemm* p, void* stream);
  * candidates the planner does not pick), -1 for the 128x128-family kernels (two stages of 64-deep slabs) on the tile they
  * choose by workgroup count, -2 for that kernel on a 128x160 tile, -4 for the A-stationary kernel (K = 320 linear layers over
  * 24576 .. 65536 rows: one workgroup per CU keeps its 128 activation rows in registers, weights stream in 64-column strips);
+ * -5 for the row-vector kernel (M <= 4 rows, linear gather: the timestep / frame-stride MLPs of openaimodel3d.py:583-592 -- a
+ * matrix-vector product bound by reading W once, one wave per 4 output columns);
  * *split = split-K factor. */
 int ccv_gemm_plan(const CcvGemm* p, int32_t* tile, int32_t* split);
 /* 1 when ccv_gemm can run this problem with its LayerNorm prologue (p->ln_gamma set), 0 when the caller must normalise first. */

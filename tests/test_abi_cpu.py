@@ -109,6 +109,8 @@ def test_gemm_epilogue_groupnorm_slots_host_logic(built):
 def test_gemm_planner_host_logic(built):
     """Kernel selection is host code (no device work): the model's layer classes map to the kernels the sweep
     in profiles/ found fastest, and the workspace request always matches the planned split."""
+    assert _plan(built, 1, 21120, 1280) == (-5, 1) and _plan(built, 4, 1280, 320) == (-5, 1)   # <= 4 rows: the row-vector kernel
+    assert _plan(built, 5, 1280, 320)[0] != -5
     assert _plan(built, 32768, 960, 320) == (-4, 1)                      # QKV projection at 32x32 latents (K = 320, M = 256 x 128): A-stationary kernel
     assert _plan(built, 32768, 2560, 320, geglu=1) == (-4, 1)            # GEGLU up-projection there: the same
     assert _plan(built, 16384, 960, 320) == (-1, 1)                      # a single (not CFG-paired) forward: 128 row tiles would idle half the chip

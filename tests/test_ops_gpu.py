@@ -74,6 +74,32 @@ def test_gemm_fp32_a_residual_act(ops):
         assert_close(out, fn(a.to(torch.bfloat16).float() @ w.float().t()), 1e-2, f"act {act}")
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("a_f32", [False, True])
+def test_gemm_row_vector_kernel(ops, M, a_f32, monkeypatch):
+    """M <= 4 rows (the timestep / frame-stride MLPs, the fused ResBlock embedding projection) take the row-vector kernel: same
+    epilogues as the tiled kernels, checked against torch fp32 and against the tiled kernel itself (CCV_GEMM_SKINNY=0 is read once
+    per process, so the tiled result comes from M = 5 rows with the first M compared)."""
+    ops.TRACK_GEMM_PLAN = True
+    try:
+        for (N, K) in ((1280, 320), (1280, 1280), (21120, 1280), (64, 64)):
+            a = rnd(M, K, seed=40 + M, dtype=torch.float32 if a_f32 else torch.bfloat16)
+            w, bias = rnd(N, K, seed=41, scale=0.05), rnd(N, seed=42, dtype=torch.float32)
+            ref = a.to(torch.bfloat16).float() @ w.float().t() + bias
+            out = ops.gemm(a, w, bias=bias, out_f32=True)
+            assert ops.LAST_GEMM_PLAN == (-5, 1), ops.LAST_GEMM_PLAN
+            assert_close(out, ref, 2e-3, f"row vector {M}x{N}x{K} fp32 out")
+            assert_close(ops.gemm(a, w, bias=bias, act=ops.ACT_SILU), F.silu(ref), 1e-2, "row vector + SiLU, bf16 out")
+            res = rnd(M, N, seed=43, dtype=torch.float32)
+            assert_close(ops.gemm(a, w, bias=bias, residual=res, out_f32=True), ref + res, 2e-3, "row vector + residual")
+            a5 = a.repeat(5, 1)[:5].contiguous()
+            tiled = ops.gemm(a5, w, bias=bias, out_f32=True)
+            assert ops.LAST_GEMM_PLAN[0] != -5
+            assert_close(out, tiled[:M], 1e-3, "row vector vs tiled kernel")
+    finally:
+        ops.TRACK_GEMM_PLAN = False
+
+
 def test_gemm_bias2_strided(ops):
     M, N, K, nb = 2048, 320, 320, 2
     a, w = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.05)
