@@ -210,6 +210,8 @@ def timed_clips(sample_fn, steps, warmup, dist=None, sync=None, after=None, lane
         dist.all_gather(every, tt)                       # every rank's own wall time (the line reports them all)
         PER_RANK_S[:] = [float(t[1].item()) for t in every]
         worst = max(float(t[0].item()) for t in every)
+    else:
+        PER_RANK_S[:] = [own]
     return worst, mine, out, extra
 
 
