@@ -110,7 +110,10 @@ def build(kind, M, N, K, flavour):
 def main():
     min_gain = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
     total_auto = total_best = 0.0
+    min_m = int(os.environ.get("CCV_SWEEP_MIN_M", "0"))
     for kind, M, N, K, flavour, count in SHAPES:
+        if M < min_m:
+            continue
         fn, flops, out = build(kind, M, N, K, flavour)
         setenv()
         fn(0)
