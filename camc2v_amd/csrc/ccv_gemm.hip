@@ -508,6 +508,24 @@ struct WaitSlab<PER, 0> {
 };
 
 
+#ifdef CCV_FAMILY_STAMPS
+// Diagnostic build (tools/family_stamps.py; never the shipped library): lane 0 of every wave of gemm_dma_kernel's two-stage loop
+// stamps s_memtime (low 32 bits) at five points of every slab into a spare 4 KiB of LDS (ds_write by inline assembly: a C++ LDS
+// store in a loop with LDS-DMA makes hipcc drain vmcnt) and the stamps are copied out when the tile is done.
+constexpr int FAM_STAMP_SLABS = 48, FAM_STAMP_POINTS = 5, FAM_STAMP_WORDS = FAM_STAMP_SLABS * FAM_STAMP_POINTS + 4;
+__device__ unsigned int* g_fam_stamps = nullptr;
+extern "C" int ccv_debug_family_stamps(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fam_stamps), &buf, sizeof(buf));
+}
+__device__ __forceinline__ void fam_stamp(uint32_t lds_addr, int lane) {
+    const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime();
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr), "v"(t) : "memory");
+}
+#define FAM_STAMP(slab, point) do { if ((slab) < FAM_STAMP_SLABS) fam_stamp(stamp_base + 4 * ((slab) * FAM_STAMP_POINTS + (point)), lane); } while (0)
+#else
+#define FAM_STAMP(slab, point) do { } while (0)
+#endif
+
 // ST = LDS stages: 2 = the loop above (DMA of slab s+1 behind the MFMAs of slab s, drained before every barrier); 3 = ring with
 // counted waits (two slabs in flight, s_waitcnt vmcnt(N) + raw s_barrier, as gemm_ring_kernel but with whole 128-byte rows): for
 // the layers whose time is the sum of their slabs' DMA latencies -- few tiles (<= 1 workgroup per CU anyway) and 10-80 slabs, the
@@ -656,16 +674,29 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
         }
     };
     if constexpr (ST == 2) {
+#ifdef CCV_FAMILY_STAMPS
+        const uint32_t stamp_base = (uint32_t)(uintptr_t)(lptr_t*)(smem + ST * (BM + BN) * 128) + wave * (FAM_STAMP_WORDS * 4);
+        FAM_STAMP(0, 0);          // (slab 0, point 0 is overwritten below: the kernel's first stamp goes to the spare words)
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(stamp_base + 4 * (FAM_STAMP_SLABS * FAM_STAMP_POINTS)), "v"((uint32_t)__builtin_amdgcn_s_memtime()) : "memory");
+#endif
         issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int s = s_begin; s < s_end; ++s) {
             const int buf = (s - s_begin) & 1;
+            FAM_STAMP(s - s_begin, 0);                 // top of the slab
             if (s + 1 < s_end) issue(buf ^ 1);
+            FAM_STAMP(s - s_begin, 1);                 // next slab's DMA issued
             multiply(buf);
+            FAM_STAMP(s - s_begin, 2);                 // fragment reads done, all MFMAs issued
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FAM_STAMP(s - s_begin, 3);                 // next slab landed (this wave's pieces)
             __syncthreads();
+            FAM_STAMP(s - s_begin, 4);                 // past the barrier
         }
+#ifdef CCV_FAMILY_STAMPS
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(stamp_base + 4 * (FAM_STAMP_SLABS * FAM_STAMP_POINTS + 1)), "v"((uint32_t)__builtin_amdgcn_s_memtime()) : "memory");
+#endif
     } else {
         // ring: ST-1 slabs in flight.  Top of iteration s: slab s has landed (the younger ones may still fly), every wave is past
         // its reads of slab s-1 (program order + barrier), whose stage therefore takes slab s+ST-1.
@@ -682,6 +713,17 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
         __syncthreads();   // (the statistics tail reuses the operand stages)
     }
 
+#ifdef CCV_FAMILY_STAMPS
+    if constexpr (ST == 2) {
+        if (g_fam_stamps != nullptr) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned int* src = reinterpret_cast<const unsigned int*>(smem + ST * (BM + BN) * 128) + wave * FAM_STAMP_WORDS;
+            unsigned int* dst = g_fam_stamps + ((long)blockIdx.x * 4 + wave) * FAM_STAMP_WORDS;
+            for (int i = lane; i < FAM_STAMP_WORDS; i += 64) dst[i] = src[i];
+            if (lane == 0) { dst[FAM_STAMP_SLABS * FAM_STAMP_POINTS + 2] = (unsigned)(s_end - s_begin); dst[FAM_STAMP_SLABS * FAM_STAMP_POINTS + 3] = (unsigned)__builtin_amdgcn_s_memtime(); }
+        }
+    }
+#endif
     if constexpr (GN) {      // statistics-emitting instance (launched only with p.gn_partial set and no split-K): its own epilogue
         tile_epilogue_gn<MT, NT>(p, acc, m0, n0, tiles_n, smem);
         return;
@@ -1164,7 +1206,11 @@ int launch_dma(const CcvGemm& p, hipStream_t st) {
             if (stages >= 3) return launch_dma_ring<MT, NT, GATHER, 3>(p, st);     // (4 stages measured equal to 3: not instantiated)
         }
     }
+#ifdef CCV_FAMILY_STAMPS
+    const size_t lds = 2 * (BM + BN) * 128 + 4 * FAM_STAMP_WORDS * 4;
+#else
     const size_t lds = 2 * (BM + BN) * 128;
+#endif
     if constexpr (gn_dma_tile(MT, NT, GATHER)) {
         if (p.gn_partial && p.split_k <= 1) {   // the statistics-emitting instance (split-K: the reduce kernel emits them)
             auto kern_gn = gemm_dma_kernel<MT, NT, GATHER, true>;
