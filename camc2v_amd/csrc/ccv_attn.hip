@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
     __shared__ __attribute__((aligned(16))) unsigned char sV[KT * V_ROW];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar for the compiler (M0 of the K/V DMA)
     const int r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.z, head = blockIdx.y, qblk = blockIdx.x;
     const long bo = b / p.inner, bi = b % p.inner;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     static_assert(!(MASKED && TWO), "the two-context form has no mask path");
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar for the compiler (M0 of the K/V DMA)
     const int r = lane & 31, hh = lane >> 5;
     int qblk, head, b;
     attn_block_coords((p.Lq + 255) / 256, p.H, qblk, head, b);

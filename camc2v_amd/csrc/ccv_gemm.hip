@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA destinations (M0) stay scalar
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler: LDS-DMA destinations (M0) stay scalar
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = p.N / BN;
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     static_assert(MT == 2 && NT == 2, "operand lists of the counted waits below");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar for the compiler (M0 of the weight DMA)
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
     const int m0 = blockIdx.x * BM;
