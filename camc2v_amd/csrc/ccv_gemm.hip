@@ -489,6 +489,9 @@ __device__ __attribute__((aligned(16))) unsigned char g_zero_line[16];
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
+// LDS-DMA through buffer descriptors (gemm_dma_kernel / gemm_ring_kernel): the descriptors span DMA_RANGE bytes from the operand's
+// base (the host checks that every real row lies below it), DMA_NOWHERE is the per-lane offset of a row that does not exist.
+constexpr int DMA_RANGE = 0x7ff00000, DMA_NOWHERE = 0x7ffffff0;
 
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
@@ -532,6 +535,7 @@ __device__ __forceinline__ void fam_stamp(uint32_t lds_addr, int lane) {
 // 8x8 / 4x4-latent linear layers and temporal convolutions: a two-stage loop pays one exposed L2 / HBM round trip per slab.
 template <int MT, int NT, int GATHER, bool GN = false, int ST = 2>   // GN: instances whose epilogue is tile_epilogue_gn (their own kernels: it costs
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 15-50 VGPRs, which the plain instances must not pay)
+#if defined(__HIP_DEVICE_COMPILE__)   // (the buffer-descriptor builtins and their type exist in the device pass only; the host pass needs the stub)
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 32, BI = BN / 32;  // DMA wave-instructions per wave and slab (8 rows each)
     static_assert(ST == 2 || ST == 3 || ST == 4, "stages");
@@ -580,23 +584,23 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
     const int nslab_all = p.taps * slabs_per_tap;
     const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
     const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
-    const uint16_t* A = static_cast<const uint16_t*>(p.A);
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
-    // Per-lane DMA source pointers advance by one slab per issue; the gather is re-evaluated only when the tap
-    // changes (9 / 3 / 1 times per tile), so the steady-state loop carries two 64-bit adds per DMA instruction
-    // instead of the divisions, bounds tests and 64-bit multiplies of the gather.
-    const uint16_t* b_ptr[BI];
-    int b_step[BI];
+    // Operands reach LDS through raw buffer descriptors (buffer_load_dwordx4 ... offen lds): a lane's source is base + its own 32-bit
+    // byte offset (fixed per tap: the gather is re-evaluated 9 / 3 / 1 times per tile) + ONE scalar offset that walks K, so the
+    // steady-state loop has no per-lane address arithmetic at all (the 64-bit pointer per piece it replaces cost two vector
+    // instructions per piece and slab); rows that do not exist -- zero padding of a convolution, rows past M or N -- carry an
+    // offset past the descriptor's range and the hardware writes zeros for them (tools/probes/buffer_lds_oob_probe.hip).
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, DMA_RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, DMA_RANGE, 0x00020000);
+    int b_off[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         const int r = 8 * (4 * j + wave) + lrow;
         const int n = n0 + r;
-        const bool ok = n < p.N;
-        b_ptr[j] = ok ? p.W + (long)n * ldw + (long)s_begin * BK + (lchunk ^ ((r >> 1) & 7)) * 8 : zero;
-        b_step[j] = ok ? BK : 0;
+        b_off[j] = (n < p.N) ? (int)(((long)n * ldw + (lchunk ^ ((r >> 1) & 7)) * 8) * 2) : DMA_NOWHERE;
     }
-    const uint16_t* a_ptr[AI];
-    int a_step[AI];
+    int w_soff = s_begin * BK * 2;      // scalar byte offsets along K: the weights', and the activations' inside the current tap
+    int a_soff = 0;
+    int a_off[AI];
     auto set_tap = [&](int tap, int kc) {
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
@@ -617,9 +621,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
                     src = (long)a_base[j] + (long)tap * p.hw;   // segment `tap` of the stacked operand
                 }
             }
-            a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
-            a_step[j] = (src >= 0) ? BK : 0;
+            a_off[j] = (src >= 0) ? (int)((src * p.lda + a_col[j]) * 2) : DMA_NOWHERE;
         }
+        a_soff = kc * 2;
     };
     int tap_cur = s_begin / slabs_per_tap;
     int slab_in_tap = s_begin - tap_cur * slabs_per_tap;
@@ -632,15 +636,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
             set_tap(tap_cur, 0);
         }
 #pragma unroll
-        for (int j = 0; j < AI; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t*)a_ptr[j], (lptr_t*)(sA + (buf * BM + 8 * (4 * j + wave)) * 128), 16, 0, 0);
-            a_ptr[j] += a_step[j];
-        }
+        for (int j = 0; j < AI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t*)(sA + (buf * BM + 8 * (4 * j + wave)) * 128), 16, a_off[j], a_soff, 0, 0);
 #pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t*)b_ptr[j], (lptr_t*)(sB + (buf * BN + 8 * (4 * j + wave)) * 128), 16, 0, 0);
-            b_ptr[j] += b_step[j];
-        }
+        for (int j = 0; j < BI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t*)(sB + (buf * BN + 8 * (4 * j + wave)) * 128), 16, b_off[j], w_soff, 0, 0);
+        a_soff += BK * 2;
+        w_soff += BK * 2;
         ++slab_in_tap;
     };
 
@@ -787,6 +789,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
             }
         });
     });
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -803,6 +806,7 @@ constexpr int RING_BK = 32;
 
 template <int MT, int NT, int ST, int GATHER, bool GN = false>
 __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void gemm_ring_kernel(const CcvGemm p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (as gemm_dma_kernel)
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int AI = BM / 64;           // A pieces (16 rows of 64 B = one DMA wave-instruction) per wave and slab
     constexpr int BP = BN / 16;           // B pieces per slab in total
@@ -852,18 +856,20 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
     const int nslab_all = p.taps * slabs_per_tap;
     const int s_begin = (p.split_k > 1) ? (int)((long)nslab_all * split / p.split_k) : 0;
     const int s_end = (p.split_k > 1) ? (int)((long)nslab_all * (split + 1) / p.split_k) : nslab_all;
-    const uint16_t* A = static_cast<const uint16_t*>(p.A);
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
-    const uint16_t* b_ptr[BI];
+    // buffer descriptors + per-lane 32-bit offsets + one scalar K offset, as in gemm_dma_kernel
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, DMA_RANGE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, DMA_RANGE, 0x00020000);
+    int b_off[BI];
     int b_piece[BI];
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
         b_piece[j] = min(4 * j + wave, BP - 1);
         const int r = 16 * b_piece[j] + lrow;
-        b_ptr[j] = p.W + (long)(n0 + r) * ldw + (long)s_begin * RING_BK + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8;
+        b_off[j] = (int)(((long)(n0 + r) * ldw + (lchunk ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)) * 8) * 2);
     }
-    const uint16_t* a_ptr[AI];
-    int a_step[AI];
+    int w_soff = s_begin * RING_BK * 2;
+    int a_soff = 0;
+    int a_off[AI];
     auto set_tap = [&](int tap, int kc) {   // gather re-evaluated only when the tap changes
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
@@ -884,9 +890,9 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
                     src = (long)a_base[j] + (long)tap * p.hw;   // segment `tap` of the stacked operand
                 }
             }
-            a_ptr[j] = (src >= 0) ? A + src * p.lda + kc + a_col[j] : zero;
-            a_step[j] = (src >= 0) ? RING_BK : 0;
+            a_off[j] = (src >= 0) ? (int)((src * p.lda + a_col[j]) * 2) : DMA_NOWHERE;
         }
+        a_soff = kc * 2;
     };
     int tap_cur = s_begin / slabs_per_tap;
     int slab_in_tap = s_begin - tap_cur * slabs_per_tap;
@@ -901,15 +907,13 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
         unsigned char* sA = smem + stage * STAGE_BYTES;
         unsigned char* sB = sA + BM * RING_BK * 2;
 #pragma unroll
-        for (int j = 0; j < AI; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t*)a_ptr[j], (lptr_t*)(sA + 16 * (4 * j + wave) * 64), 16, 0, 0);
-            a_ptr[j] += a_step[j];
-        }
+        for (int j = 0; j < AI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t*)(sA + 16 * (4 * j + wave) * 64), 16, a_off[j], a_soff, 0, 0);
 #pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t*)b_ptr[j], (lptr_t*)(sB + 16 * b_piece[j] * 64), 16, 0, 0);
-            b_ptr[j] += RING_BK;
-        }
+        for (int j = 0; j < BI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t*)(sB + 16 * b_piece[j] * 64), 16, b_off[j], w_soff, 0, 0);
+        a_soff += RING_BK * 2;
+        w_soff += RING_BK * 2;
         ++slab_in_tap;
     };
 
@@ -1004,6 +1008,7 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             }
         });
     });
+#endif
 }
 
 // split-K second pass: sum the partial slabs and run the epilogue; one thread per 4 output columns
@@ -2019,6 +2024,13 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(!p.gn_partial || (p.gn_rows > 0 && p.gn_slots > 0 && p.gn_slots == ccv_gemm_gn_slots(&p, p.gn_rows) &&
                                   (ccv_gemm_ws_bytes(&p) == 0 || p.split_k > 1)), CCV_EINVAL,
                 "ccv_gemm: gn_partial needs gn_rows and gn_slots = ccv_gemm_gn_slots() > 0 for this problem (got rows %d, slots %d)", p.gn_rows, p.gn_slots);
+    {   // the LDS-DMA kernels address both operands with 32-bit byte offsets from their base (buffer descriptors)
+        long a_rows = p.M;
+        if (p.gather == 1 && p.out_h > 0 && p.out_w > 0) a_rows = (long)(p.M / (p.out_h * p.out_w)) * p.src_h * p.src_w;
+        else if (p.gather == 3) a_rows = (long)(p.taps - 1) * p.hw + p.M;
+        CCV_REQUIRE(a_rows * p.lda * (p.a_f32 ? 4 : 2) < (long)DMA_RANGE && (long)p.N * p.taps * p.K * 2 < (long)DMA_RANGE, CCV_ESHAPE,
+                    "ccv_gemm: an operand spans 2 GiB or more (activations %ld rows x %d, weights %d x %d)", a_rows, p.lda, p.N, p.taps * p.K);
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     CCV_REQUIRE(p.ln_gamma == nullptr || (plan_ok(p) && astat_fits(p)), CCV_ESHAPE,
                 "ccv_gemm: the LayerNorm prologue (ln_gamma) exists in the A-stationary kernel only: ask ccv_gemm_ln_fusable() first");
