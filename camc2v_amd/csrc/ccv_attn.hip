@@ -446,6 +446,24 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         else { kb_ = kmain; vb_ = vmain; kls = p.k_ls; vls = p.v_ls; len = p.Lk; k0 = (it - n_reg) * KT; }
         unsigned char* sK = sm + stage * (2 * KT * 128);
         unsigned char* sV = sK + KT * 128;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((p.perm_w == 0 || it < n_reg || (TWO && it >= n_first)) && ((long)(len - 1) * kls + 64) * 2 < 0x7ff00000l && ((long)(len - 1) * vls + 64) * 2 < 0x7ff00000l) {
+            // keys stored in the order they are visited: the tile through buffer descriptors over this (batch, head) slice -- a lane's
+            // offset is row * stride + its swizzled column, the tile's first row rides in the scalar offset, and rows past the last key
+            // fall outside the descriptor's range: the hardware writes zeros for them (no zero line, no per-lane pointer arithmetic)
+            const int kls32 = (int)kls, vls32 = (int)vls;
+            const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kb_), 0, ((len - 1) * kls32 + 64) * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vb_), 0, ((len - 1) * vls32 + 64) * 2, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int piece = wave * 2 + j;             // 8 rows of 128 B
+                const int row = 8 * piece + (lane >> 3), pc = lane & 7;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lptr_t*)(sK + piece * 1024), 16, (row * kls32 + ((pc ^ ((row >> 1) & 7)) << 3)) * 2, k0 * kls32 * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lptr_t*)(sV + piece * 1024), 16, (row * vls32 + ((pc ^ (((row >> 1) & 1) << 2)) << 3)) * 2, k0 * vls32 * 2, 0, 0);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int piece = wave * 2 + j;             // 8 rows of 128 B
