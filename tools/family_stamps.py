@@ -31,8 +31,8 @@ WORDS = SLABS * POINTS + 4
 SHAPES = [  # kind, M, N, K, forced family tile (10 MT + NT), split
     ("conv", 32768, 320, 320, 45, 1), ("conv", 8192, 640, 640, 45, 2), ("tconv", 32768, 320, 320, 45, 1),
     ("lin", 32768, 320, 1280, 45, 1), ("lin", 8192, 1920, 640, 45, 1), ("lin", 8192, 640, 640, 42, 1), ("lin", 2048, 1280, 1280, 42, 1),
-    ("lin", 8192, 1920, 640, 44, 1),
-]
+    ("lin", 8192, 1920, 640, 44, 1), ("linres", 8192, 640, 640, 42, 1), ("linres", 2048, 1280, 1280, 42, 1), ("linres", 32768, 320, 1280, 45, 1),
+]      # linres: the fp16 residual stream read-modify-written in the epilogue
 
 
 def main():
@@ -51,6 +51,9 @@ def main():
         else:
             W = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        if kind == "linres":
+            stream = torch.randn(M, N, device=dev).to(torch.float16)
+            kw = dict(residual=stream, out_dtype=torch.float16, out=torch.empty_like(stream), bias=torch.zeros(N, device=dev))
         os.environ.update(CCV_GEMM_RING="-1", CCV_GEMM_FAMTILE=str(ft), CCV_GEMM_ST="2", CCV_GEMM_SPLIT=str(sp))
         bm, bn = 32 * (ft // 10), 32 * (ft % 10)
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * sp
@@ -85,13 +88,13 @@ def main():
         slab = d(st[:, :, 1:, 0] - st[:, :, :-1, 0]) if n > 1 else issue
         first = d(st[:, :, 0, 0] - t[:, :, SLABS * POINTS])           # kernel start -> first slab ready (prologue: gather setup + first DMA round trip)
         total = d(t[:, :, SLABS * POINTS + 3] - t[:, :, SLABS * POINTS])
+        epi = d(t[:, :, SLABS * POINTS + 3] - t[:, :, SLABS * POINTS + 1])
         mfma_cyc = (ft // 10) * (ft % 10) * 2 * 16          # this wave's MFMAs per slab x 16 cycles
         med = lambda x: float(np.median(x))
         print(f"{kind:5s} M={M:6d} N={N:5d} K={K:5d} tile {bm}x{bn} split {sp} plan {plan}: {tiles} workgroups, {nslab} slabs each; {t_plain:.1f} us plain, {t_stamped:.1f} us stamped\n"
               f"    per slab (median cycles over waves x slabs): DMA issue {med(issue):.0f} | fragment reads + MFMA issue {med(mult):.0f} "
               f"(the wave's own MFMAs: {mfma_cyc}) | vmcnt(0) {med(wait):.0f} | barrier {med(barrier):.0f} | slab to slab {med(slab):.0f}\n"
-              f"    per tile: prologue (gather setup + first DMA round trip) {med(first):.0f} | main loop {med(slab) * n:.0f} | start to end of the main loop {med(total):.0f} "
-              f"(the epilogue follows)", flush=True)
+              f"    per tile: prologue (gather setup + first DMA round trip) {med(first):.0f} | main loop {med(slab) * n:.0f} | epilogue (to the issue of its last store) {med(epi):.0f} | whole wave {med(total):.0f}", flush=True)
 
 
 if __name__ == "__main__":
