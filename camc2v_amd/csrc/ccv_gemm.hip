@@ -715,17 +715,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
         __syncthreads();   // (the statistics tail reuses the operand stages)
     }
 
-#ifdef CCV_FAMILY_STAMPS
-    if constexpr (ST == 2) {
-        if (g_fam_stamps != nullptr) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned int* src = reinterpret_cast<const unsigned int*>(smem + ST * (BM + BN) * 128) + wave * FAM_STAMP_WORDS;
-            unsigned int* dst = g_fam_stamps + ((long)blockIdx.x * 4 + wave) * FAM_STAMP_WORDS;
-            for (int i = lane; i < FAM_STAMP_WORDS; i += 64) dst[i] = src[i];
-            if (lane == 0) { dst[FAM_STAMP_SLABS * FAM_STAMP_POINTS + 2] = (unsigned)(s_end - s_begin); dst[FAM_STAMP_SLABS * FAM_STAMP_POINTS + 3] = (unsigned)__builtin_amdgcn_s_memtime(); }
-        }
-    }
-#endif
     if constexpr (GN) {      // statistics-emitting instance (launched only with p.gn_partial set and no split-K): its own epilogue
         tile_epilogue_gn<MT, NT>(p, acc, m0, n0, tiles_n, smem);
         return;
@@ -789,6 +778,17 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
             }
         });
     });
+#ifdef CCV_FAMILY_STAMPS
+    if constexpr (ST == 2) {
+        if (g_fam_stamps != nullptr) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned int* src = reinterpret_cast<const unsigned int*>(smem + ST * (BM + BN) * 128) + wave * FAM_STAMP_WORDS;
+            unsigned int* dst = g_fam_stamps + ((long)blockIdx.x * 4 + wave) * FAM_STAMP_WORDS;
+            for (int i = lane; i < FAM_STAMP_WORDS; i += 64) dst[i] = src[i];
+            if (lane == 0) { dst[FAM_STAMP_SLABS * FAM_STAMP_POINTS + 2] = (unsigned)(s_end - s_begin); dst[FAM_STAMP_SLABS * FAM_STAMP_POINTS + 3] = (unsigned)__builtin_amdgcn_s_memtime(); }   // behind the epilogue's last store
+        }
+    }
+#endif
 #endif
 }
 
