@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t pack_out2(const CcvGemm& p, float lo, float 
     return p.out_f32 == 2 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
 }
 
-__device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, float o[4]) {
+__device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, float o[4], bool add_residual = true) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] *= p.alpha;
     if (p.bias) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
     }
-    if (p.residual) {
+    if (p.residual && add_residual) {
         if (p.res_f16) {
             const uint2 rv = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.residual) + (long)m * p.ldr + n);
             const float2 a = unpack_f16x2(rv.x), b = unpack_f16x2(rv.y);
@@ -132,6 +132,62 @@ __device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, c
     *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = geglu_value(p, n, a_, g_);
 }
 
+
+// Row-coalescing epilogue of gemm_dma_kernel for two-byte outputs (bf16 / fp16), with or without an fp16 residual.  In the MFMA
+// fragment layout a store instruction covers 16 rows x 32-64 bytes; at the end of a launch every workgroup does that at once and the
+// burst runs at the write path's rate for partial lines (profiles/r03_family_kernel_stamps.txt: 14-32 thousand cycles per tile).  Here
+// the tile goes through LDS (the operand stages are free by now): the residual tile comes in with whole-row 16-byte loads, every lane
+// adds its fragments' values (read from LDS, fp32 arithmetic, ONE rounding, as in the direct epilogue: bit-identical results), puts the
+// packed result back in place, and the tile leaves with whole-row 16-byte stores (tools/probes/store_pattern_probe.hip: 1.2-1.45x the
+// rate of the fragment pattern).  Needs 16-byte aligned rows of C (and of the residual); the caller falls back otherwise.  The
+// statistics-emitting instances keep the direct stores: the same route through LDS measured -0.6 ... +1.7 % there (box noise).
+template <int MT, int NT>
+__device__ __forceinline__ bool rows_epilogue_ok(const CcvGemm& p) {
+    return p.out_f32 != 1 && !p.geglu && p.split_k <= 1 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+           (!p.residual || (p.res_f16 && (p.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(p.residual) & 15) == 0));
+}
+template <int MT, int NT>
+__device__ __forceinline__ void tile_epilogue_rows(const CcvGemm& p, const f32x4 (&acc)[MT][NT], int m0, int n0, unsigned char* smem) {
+    constexpr int BM = 32 * MT, BN = 32 * NT, CPR = BN / 8, PITCH = BN * 2 + 16;     // 16-byte chunks per tile row; LDS row pitch in bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, fr = lane & 15, fg = lane >> 4;
+    const bool rmw = p.residual != nullptr;
+    __syncthreads();      // every wave is past its last fragment read of the operand stages
+    if (rmw) {
+        const uint16_t* R = static_cast<const uint16_t*>(p.residual);
+        for (int c = tid; c < BM * CPR; c += 256) {
+            const int row = c / CPR, col = 8 * (c - row * CPR), m = m0 + row, n = n0 + col;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (m < p.M && n < p.N) v = *reinterpret_cast<const uint4*>(R + (long)m * p.ldr + n);
+            *reinterpret_cast<uint4*>(smem + row * PITCH + col * 2) = v;
+        }
+        __syncthreads();
+    }
+    static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const int rl = wm * 16 * MT + 16 * i + fr, m = m0 + rl;
+        static_for<0, NT, 1>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            const int cl = wn * 16 * NT + 16 * j + 4 * fg, n = n0 + cl;
+            if (m < p.M && n < p.N) {
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue_math(p, m, n, o, false);
+                uint2* slot = reinterpret_cast<uint2*>(smem + rl * PITCH + cl * 2);
+                if (rmw) {
+                    const uint2 rv = *slot;
+                    const float2 a = unpack_f16x2(rv.x), b = unpack_f16x2(rv.y);
+                    o[0] += a.x; o[1] += a.y; o[2] += b.x; o[3] += b.y;
+                }
+                *slot = make_uint2(pack_out2(p, o[0], o[1]), pack_out2(p, o[2], o[3]));
+            }
+        });
+    });
+    __syncthreads();
+    uint16_t* Cp = static_cast<uint16_t*>(p.C);
+    for (int c = tid; c < BM * CPR; c += 256) {
+        const int row = c / CPR, col = 8 * (c - row * CPR), m = m0 + row, n = n0 + col;
+        if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(Cp + (long)m * p.ldc + n) = *reinterpret_cast<const uint4*>(smem + row * PITCH + col * 2);
+    }
+}
 
 // Epilogue of the statistics-emitting kernel instances (p.gn_partial; the output feeds a GroupNorm(32)): the normal epilogue
 // (alpha, bias, bias2, residual, store as bf16 / fp16 / fp32) AND the sums and sums of squares of every group's channels over this
@@ -717,6 +773,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
 
     if constexpr (GN) {      // statistics-emitting instance (launched only with p.gn_partial set and no split-K): its own epilogue
         tile_epilogue_gn<MT, NT>(p, acc, m0, n0, tiles_n, smem);
+        return;
+    }
+    if (rows_epilogue_ok<MT, NT>(p)) {
+        tile_epilogue_rows<MT, NT>(p, acc, m0, n0, smem);
         return;
     }
     const bool wide = wide_bf16_ok(p);
