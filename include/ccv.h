@@ -77,7 +77,9 @@ const char* ccv_last_error(void);
  *      geglu: W rows are interleaved in 16-row blocks (value block, gate block); the output
  *             has N/2 columns = value * gelu_erf(gate);
  *      v += residual[m][n] (fp32, or fp16 with res_f16); store bf16, fp32 or fp16 (out_f32 = 0 / 1 / 2) at C[m*ldc + n].
- * Constraints: K % 64 == 0, N % 16 == 0 (N % 32 for geglu), lda/ldc/ldr % 8 == 0.
+ * Constraints: K % 64 == 0, N % 16 == 0 (N % 32 for geglu), lda/ldc/ldr % 8 == 0; the activation operand (all rows a gather may
+ * touch) and the packed weights each span less than 2 GiB: the LDS-DMA kernels address them with 32-bit byte offsets from their base
+ * (buffer descriptors; rows that do not exist -- padding, rows past M / N -- are zero-filled by the hardware's range check).
  * ------------------------------------------------------------------------------------ */
 typedef struct CcvGemm {
     const void* A;
