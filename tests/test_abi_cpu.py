@@ -60,6 +60,18 @@ def test_argument_errors_are_reported_not_thrown(built):
     assert rc == -1 and b"null" in built.lib().ccv_last_error()
 
 
+def test_gemm_refuses_operands_of_2_gib_or_more(built):
+    """The LDS-DMA kernels address both operands with 32-bit byte offsets from their base (buffer descriptors): ccv_gemm reports
+    an operand that spans 2 GiB or more as a shape error before any device work (the pointers below are never dereferenced)."""
+    p = built.CcvGemm()
+    p.A = p.W = p.C = 0x1000
+    p.M, p.N, p.K, p.taps = 1 << 21, 320, 1024, 1
+    p.lda, p.ldc = 1024, 320                       # activations: 2^21 rows x 2 KiB = 4 GiB
+    p.alpha = 1.0
+    rc = built.lib().ccv_gemm(ctypes.byref(p), None)
+    assert rc < 0 and b"2 GiB" in built.lib().ccv_last_error()
+
+
 def test_streams_in_flight_hint_round_trips(built):
     assert built.lib().ccv_set_streams_in_flight(2) == 1       # default: one launch stream
     assert built.lib().ccv_set_streams_in_flight(0) == 2       # clamped to >= 1
