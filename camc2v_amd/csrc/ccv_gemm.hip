@@ -211,6 +211,21 @@ __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes
     return v;
 }
 
+// o[0..3] rounded to the two-byte output type: the packed values, and o[] replaced by the values as stored
+__device__ __forceinline__ uint2 round_pack(const CcvGemm& p, float o[4]) {
+    uint2 pk;
+    if (p.out_f32 == 2) {
+        pk = make_uint2(pack_f16x2(o[0], o[1]), pack_f16x2(o[2], o[3]));
+        const float2 a = unpack_f16x2(pk.x), b = unpack_f16x2(pk.y);
+        o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+    } else {
+        pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        o[0] = __uint_as_float(pk.x << 16); o[1] = __uint_as_float(pk.x & 0xffff0000u);
+        o[2] = __uint_as_float(pk.y << 16); o[3] = __uint_as_float(pk.y & 0xffff0000u);
+    }
+    return pk;
+}
+
 // store o[0..3] at C[m][n..n+3] in the output type and hand back the values as stored
 __device__ __forceinline__ void store_rounded(const CcvGemm& p, int m, int n, float o[4]) {
     if (p.out_f32 == 1) {
@@ -235,18 +250,40 @@ __device__ __forceinline__ void tile_epilogue_gn(const CcvGemm& p, const f32x4 (
     float gs[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j) gs[j][0] = gs[j][1] = gs[j][2] = gs[j][3] = 0.f;
+    const bool wide = wide_bf16_ok(p);
     static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const int m = m0 + wm * 16 * MT + 16 * i + fr;      // every row is inside M (host check)
-        static_for<0, NT, 1>([&](auto J) __attribute__((always_inline)) {
-            constexpr int j = decltype(J)::value;
+        static_for<0, NT, 2>([&](auto J) __attribute__((always_inline)) {      // fragments two at a time: one 16-byte store per lane
+            constexpr int j = decltype(J)::value;                              // (store_pair_bf16) where both are in range
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
             if (n < p.N) {                                   // columns past N are not stored and add nothing
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 epilogue_math(p, m, n, o);
-                store_rounded(p, m, n, o);
+                bool paired = false;
+                if constexpr (j + 1 < NT) {
+                    if (wide && n - 4 * fg + 32 <= p.N) {
+                        float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                        epilogue_math(p, m, n + 16, o1);
+                        const uint2 a = round_pack(p, o), b = round_pack(p, o1);
+                        store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, a, b);
+                        gs[j + 1][0] += o1[0] + o1[1]; gs[j + 1][1] += o1[0] * o1[0] + o1[1] * o1[1];
+                        gs[j + 1][2] += o1[2] + o1[3]; gs[j + 1][3] += o1[2] * o1[2] + o1[3] * o1[3];
+                        paired = true;
+                    }
+                }
+                if (!paired) store_rounded(p, m, n, o);
                 gs[j][0] += o[0] + o[1]; gs[j][1] += o[0] * o[0] + o[1] * o[1];
                 gs[j][2] += o[2] + o[3]; gs[j][3] += o[2] * o[2] + o[3] * o[3];
+                if constexpr (j + 1 < NT) {
+                    if (!paired && n + 16 < p.N) {
+                        float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+                        epilogue_math(p, m, n + 16, o1);
+                        store_rounded(p, m, n + 16, o1);
+                        gs[j + 1][0] += o1[0] + o1[1]; gs[j + 1][1] += o1[0] * o1[0] + o1[1] * o1[1];
+                        gs[j + 1][2] += o1[2] + o1[3]; gs[j + 1][3] += o1[2] * o1[2] + o1[3] * o1[3];
+                    }
+                }
             }
         });
     });
