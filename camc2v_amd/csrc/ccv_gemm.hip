@@ -1234,9 +1234,9 @@ inline void choose_tile(const CcvGemm& p, int& mt, int& nt) {
     // long-K problems (>= 48 slabs of 64) keep the larger tile: split-K supplies their workgroups
     // (2048x1280 with K = 3840 / 5120 in-model: 64x128 + split 2 = 47 / 58 us, 64x64 unsplit = 54 / 67 us)
     const bool long_k = p.taps * (p.K / BK) >= 48;
-    // ... unless the caller keeps a second launch stream busy (ccv_set_streams_in_flight): then one workgroup per CU is enough,
-    // the other stream's kernels hide the latency (two clips in flight: 27.5 -> 28.1 frames/s; one clip: 22.6 -> 22.0)
-    const long want = tune_env("CCV_GEMM_WANT") > 0 ? tune_env("CCV_GEMM_WANT") : ((long_k || g_streams_in_flight.load() >= 2) ? 256 : 384);
+    // (round 2 took the larger tile at one workgroup per CU whenever a second launch stream was busy: 27.5 -> 28.1 frames/s then; with
+    // round 3's cheaper DMA issue and row epilogues the smaller tiles win again with two clips in flight, 31.0 -> 31.6: profiles/r03_ab_switches.txt)
+    const long want = tune_env("CCV_GEMM_WANT") > 0 ? tune_env("CCV_GEMM_WANT") : (long_k ? 256 : 384);
     if (p.N % 128 == 0 && tiles(128, 128) >= want) { mt = 4; nt = 4; return; }
     if (p.N % 128 == 0 && tiles(64, 128) >= want) { mt = 2; nt = 4; return; }
     if (p.N % 64 == 0 && tiles(128, 64) >= (want == 256 ? 320 : want)) { mt = 4; nt = 2; return; }
