@@ -1600,6 +1600,7 @@ enum { AS_BF16_WIDE = 0, AS_BF16 = 1, AS_F32 = 2, AS_GEGLU = 3, AS_F16 = 4 };   
 // LayerNorm launch, no normalised copy of the stream in memory.
 template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (buffer-descriptor builtins: device pass only, as gemm_dma_kernel)
     // 8 waves = 4 (rows) x 2 (columns), wave tile 32 rows x 32 columns, two waves per SIMD.  Measured on the way here
     // (profiles/r02_astat_notes.txt): 4 waves of 64 rows, one per SIMD, add the phases up (knock-out: MFMA 9.6 us + stores 7.8 us
     // + weight DMA 5.3 us over a 17.8 us floor for the QKV projection, 36.4 us); 8 waves: 32.5 us; letting waves 4-7 run their
@@ -1633,17 +1634,17 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     // ---- weight strip DMA: piece q of this wave = slab q, row group `wave` (8 rows x 128 B) ---------------------------
     const int lrow = lane >> 3, lchunk = lane & 7;
     const int wr = 8 * wave + lrow;                     // row of the strip (0..63) this lane fetches
-    const uint16_t* wsrc = p.W + (long)wr * K + ((lchunk ^ ((wr >> 1) & 7)) << 3);
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_line);
-    // Past the last strip the same number of pieces is issued from the zero line (into a stage nobody reads any more): every
-    // iteration then issues exactly PIECES DMA operations, so the counted waits below hold on every path.
+    // weights through a buffer descriptor (as gemm_dma_kernel): the lane's offset inside a strip is fixed, the strip and the slab ride in
+    // the scalar offset.  Past the last strip the same number of pieces is issued with an out-of-range scalar offset (the hardware
+    // writes zeros into a stage nobody reads any more): every iteration then issues exactly PIECES DMA operations, so the counted
+    // waits below hold on every path.
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, DMA_RANGE, 0x00020000);
+    const int w_off = (wr * K + ((lchunk ^ ((wr >> 1) & 7)) << 3)) * 2;
     auto issue = [&](int strip, int stage) {
-        const bool real = strip < nstrips;
-        const long soff = (long)strip * BN * K;
+        const int soff = strip < nstrips ? strip * BN * K * 2 : DMA_NOWHERE;
 #pragma unroll
         for (int q = 0; q < PIECES; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(real ? wsrc + soff + q * 64 : zero),
-                                             (lptr_t*)(smem + stage * STAGE + (q * BN + 8 * wave) * 128), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t*)(smem + stage * STAGE + (q * BN + 8 * wave) * 128), 16, w_off, soff + q * 128, 0, 0);
     };
     // Strip s lives in ring stage (s + 2) % 3: stages 0 and 1 first hold the ACTIVATION tile, staged by LDS-DMA in whole
     // 128-byte lines (8 rows x 128 B per piece, [slab][128 rows][128 B], same source-side swizzle as the weight image) and read
@@ -1854,6 +1855,7 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
         if (stamps) stamps[4 + 3 * s] = __builtin_amdgcn_s_memtime();
     }
     wait_vm_only<0>();   // the zero-line pieces issued past the last strip target this workgroup's LDS: retire them before it is released
+#endif
 }
 
 template <int NSLAB, int MODE, bool HAS_BIAS, bool HAS_RES, bool LNF = false>
