@@ -697,6 +697,7 @@ struct SparseArgs {
 };
 
 __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (buffer-descriptor builtins: device pass only)
     const int slot = p.slot, use_xcd_queues = p.use_xcd_queues;
     // aligned(256): the seed-table address is formed as (nibble << 4) | lut (v_lshl_or_b32), which needs the low 8 bits of the table's
     // LDS address clear (table offset 0x10800 + a 256-byte aligned base)
@@ -791,13 +792,17 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
         koff[j] = step * p.k_ls + ((pc ^ ((rowin >> 1) & 7)) << 3);
         voff[j] = step * p.v_ls + ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
     }
-    long koff_m[4], voff_m[4];   // the same, minus the instruction offset of piece j (in elements)
+    // buffer descriptors over this item's K / V slice and mask rows (all uniform) + the lane's 32-bit byte offsets into them
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kmain), 0, ((p.Lk - 1) * k_ls32 + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vmain), 0, ((p.Lk - 1) * v_ls32 + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.mask_bits + (long)mb * p.mask_bs), 0, p.Lq * p.mask_words * 4, 0x00020000);
+    int koff32[4], voff32[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        koff_m[j] = koff[j] - (j * 1024 - 4096) / 2;
-        voff_m[j] = voff[j] - (j * 1024) / 2;
-        asm volatile("" : "+v"(koff_m[j]), "+v"(voff_m[j]));   // opaque: hipcc otherwise re-derives them per block with 64-bit adds
+        koff32[j] = (int)koff[j] * 2;
+        voff32[j] = (int)voff[j] * 2;
     }
+    const int moff32 = min(q0 + lane, p.Lq - 1) * p.mask_words * 4;
     auto issue = [&](int blk, int stage) __attribute__((always_inline)) {   // 8 K/V DMA pieces + 1 mask-word DMA = 9 vector-memory operations
         unsigned char* sK = ring + stage * 8192;
         unsigned char* sV = sK + 4096;
@@ -830,30 +835,20 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
                 }
                 base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
             }
-            // row strides fit 32 bits (checked on the host): one 32x32->64 multiply instead of a 64x64 one
-            const uint16_t* kp = kmain + (long)base * (long)k_ls32;
-            const uint16_t* vp = vmain + (long)base * (long)v_ls32;
-            // one M0 value (the middle of the stage) for all eight pieces: the instruction offset moves the LDS destination AND the
-            // global address, so the per-lane source offsets carry the opposite shift (koff_m / voff_m)
-#define CCV_SPARSE_PIECE(j, KSRC, VSRC)                                                                              \
-    __builtin_amdgcn_global_load_lds((gptr_t*)(KSRC), (lptr_t*)sV, 16, (j) * 1024 - 4096, 0);                       \
-    __builtin_amdgcn_global_load_lds((gptr_t*)(VSRC), (lptr_t*)sV, 16, (j) * 1024, 0);
-            if (k0 + 32 <= p.Lk) {      // every block but a ragged last one: no per-lane bounds select
-                CCV_SPARSE_PIECE(0, kp + koff_m[0], vp + voff_m[0]) CCV_SPARSE_PIECE(1, kp + koff_m[1], vp + voff_m[1])
-                CCV_SPARSE_PIECE(2, kp + koff_m[2], vp + voff_m[2]) CCV_SPARSE_PIECE(3, kp + koff_m[3], vp + voff_m[3])
-            } else {
-                const bool ok0 = (k0 + lr8) < p.Lk, ok1 = (k0 + 8 + lr8) < p.Lk, ok2 = (k0 + 16 + lr8) < p.Lk, ok3 = (k0 + 24 + lr8) < p.Lk;
-                CCV_SPARSE_PIECE(0, ok0 ? kp + koff_m[0] : zero + 2048, ok0 ? vp + voff_m[0] : zero)
-                CCV_SPARSE_PIECE(1, ok1 ? kp + koff_m[1] : zero + 1536, ok1 ? vp + voff_m[1] : zero - 512)
-                CCV_SPARSE_PIECE(2, ok2 ? kp + koff_m[2] : zero + 1024, ok2 ? vp + voff_m[2] : zero - 1024)
-                CCV_SPARSE_PIECE(3, ok3 ? kp + koff_m[3] : zero + 512, ok3 ? vp + voff_m[3] : zero - 1536)
+            // through the slice's buffer descriptors: the lane's 32-bit offsets are fixed for the item, the block's first stored row rides
+            // in the scalar offset (no vector address arithmetic per block); rows past the last key of a ragged last block (raster order
+            // only: a patch-ordered sequence is a whole number of 32-key patches, checked on the host) fall outside the descriptor's
+            // range and arrive as zeros
+            const int ks = base * k_ls32 * 2, vs = base * v_ls32 * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lptr_t*)(sK + j * 1024), 16, koff32[j], ks, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_t*)(sV + j * 1024), 16, voff32[j], vs, 0, 0);
             }
-#undef CCV_SPARSE_PIECE
         }
         // mask words of the 64 queries (lane l <-> query q0 + l) go to LDS by DMA as well: 4 bytes per lane
         const int wi = blk < 0 ? 0 : blk;
-        const uint32_t* mp = p.mask_bits + (long)mb * p.mask_bs + (long)min(q0 + lane, p.Lq - 1) * p.mask_words + wi;
-        __builtin_amdgcn_global_load_lds((gptr_t*)mp, (lptr_t*)(mwring + stage * 256), 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (lptr_t*)(mwring + stage * 256), 4, moff32, wi * 4, 0, 0);
     };
 
     float m_run[2] = {NEG_INF, NEG_INF}, l_run[2] = {0.f, 0.f};
@@ -1006,6 +1001,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
     }
   }  // next query group
   }  // next queue
+#endif
 }
 
 // =================================================================================================
@@ -1188,6 +1184,10 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             CCV_REQUIRE(p.q_ls >= 0 && p.q_ls < (1l << 31) && p.o_ls >= 0 && p.o_ls < (1l << 31) && mask_bs >= 0 && mask_bs < (1l << 31) &&
                             wave_bs >= 0 && wave_bs < (1l << 31) && order_bs >= 0 && order_bs < (1l << 31), CCV_ESHAPE,
                         "ccv_attn_fwd: sparse kernel takes 32-bit token strides and mask slice sizes");
+            // K / V blocks and mask words reach LDS through buffer descriptors over one (batch, head) slice / one mask: 32-bit byte offsets
+            CCV_REQUIRE(p.k_ls >= 0 && p.v_ls >= 0 && ((long)(p.Lk - 1) * p.k_ls + 64) * 2 < 0x7ff00000l && ((long)(p.Lk - 1) * p.v_ls + 64) * 2 < 0x7ff00000l &&
+                            (long)p.Lq * p.mask_words * 4 < 0x7ff00000l, CCV_ESHAPE, "ccv_attn_fwd: sparse kernel: a K / V slice or a mask spans 2 GiB or more");
+            CCV_REQUIRE(p.perm_w == 0 || p.Lk % 32 == 0, CCV_ESHAPE, "ccv_attn_fwd: patch-ordered keys come in whole 32-key patches (Lk = %d)", p.Lk);
             SparseArgs a;
             a.q = p.q; a.k = p.k; a.v = p.v; a.o = p.o; a.kreg = p.kreg; a.vreg = p.vreg;
             a.mask_bits = p.mask_bits; a.wave_bits = p.wave_bits; a.group_order = p.group_order; a.queue_counters = p.queue_counters;
