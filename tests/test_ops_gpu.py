@@ -927,6 +927,31 @@ def test_gemm_fp16_stream_epilogues(ops, M, N, K, taps):
     assert_close(outn, ref - res.float(), 1.5e-3, "fp16 out, no residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 640), (300, 64, 320), (8192, 640, 640), (2048, 1280, 1280)])
+def test_gemm_row_epilogue_edges_match_the_direct_epilogue(ops, M, N, K):
+    """The family kernel's epilogue through LDS rows (two-byte outputs, 16-byte aligned rows) against the direct epilogue it replaces:
+    a column slice of a wider matrix whose row pitch is NOT a multiple of 8 elements takes the direct path, and both must give the same
+    bits -- ragged M (rows past M in the last tile), N smaller than a tile, in-place fp16 stream update, bf16 output."""
+    a, w = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=0.05)
+    bias = rnd(N, seed=63, dtype=torch.float32)
+    res = _f16(rnd(M, N, seed=64, dtype=torch.float32))
+    ref = a.float() @ w.float().t() + bias + res.float()
+    rows = ops.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float16)                       # aligned: rows epilogue
+    assert_close(rows, ref, 1.5e-3, f"rows epilogue {M}x{N}x{K}")
+    wide_res = torch.zeros(M, N + 4, dtype=torch.float16, device=res.device)                       # pitch N + 4: rows only 8-byte aligned
+    wide_res[:, :N] = res
+    wide_out = torch.zeros(M, N + 4, dtype=torch.float16, device=res.device)
+    direct = ops.gemm(a, w, bias=bias, residual=wide_res[:, :N], out_dtype=torch.float16, out=wide_out[:, :N])
+    assert torch.equal(direct, rows), "direct and row epilogues differ"
+    assert torch.count_nonzero(wide_out[:, N:]) == 0, "the epilogue wrote past column N"
+    stream = res.clone()
+    ops.gemm(a, w, bias=bias, residual=stream, out_dtype=torch.float16, out=stream)
+    assert torch.equal(stream, rows), "in-place stream update differs"
+    b16 = ops.gemm(a, w, bias=bias)
+    wide_b = torch.zeros(M, N + 4, dtype=torch.bfloat16, device=res.device)
+    assert torch.equal(ops.gemm(a, w, bias=bias, out=wide_b[:, :N]), b16), "bf16: direct and row epilogues differ"
+
+
 def test_gemm_fp16_stream_convs(ops):
     """conv3x3 (+ fp16 residual) and the temporal convolution writing the fp16 stream."""
     from camc2v_amd.pack import pack_conv3x3, pack_tconv3
