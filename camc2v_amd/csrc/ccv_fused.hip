@@ -1,0 +1,330 @@
+// ccv_fused: transformer sub-blocks of the 32x32-latent layers (C = 320) as ONE launch each (gfx950).
+//
+// At 32x32 latents a transformer tensor is 32768 rows x 320 channels = 21 MB and every unfused step (LayerNorm, projection,
+// gating, projection back) is a round trip through HBM / the Infinity Cache: the chain is memory-bound, not MFMA-bound.  The kernels
+// here give one workgroup 128 token rows and keep them on the CU from the LayerNorm to the residual update.
+//
+// Shared structure (ff_fused_kernel; the temporal chain below reuses it):
+//   * 4 waves, ONE per SIMD, 32 rows each, up to 512 registers per lane: the normalised rows (80 registers of bf16 fragments at
+//     C = 320) and the [32 rows x 320 columns] fp32 output accumulators (160 registers) both stay resident;
+//   * v_mfma_f32_32x32x16_bf16 with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B operand, so that a lane
+//     holds one token row (column lane & 31 of the 32x32 result) and 16 output features ((reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
+//   * an accumulator IS the next product's B operand: registers 8 s .. 8 s + 7 converted to bf16 are the fragment of k-step s, with
+//     the k order inside a step permuted to 0-3, 8-11, 4-7, 12-15; the next weight matrix is stored with its columns permuted the
+//     same way (host, once per load), so intermediate activations never leave the register file -- no LDS round trip, no barrier;
+//   * weights stream through LDS by LDS-DMA (buffer descriptors, source-side XOR swizzle, as ccv_gemm.hip), one chunk ahead of the
+//     MFMAs; all 256 workgroups walk the same chunks in step, so after the first touch every XCD serves them from its L2.
+#include <type_traits>
+
+#include "ccv_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int B, int E, int S, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + S, E, S>(f);
+    }
+}
+
+// 128-byte LDS rows (64 bf16): 16-byte chunk c of row r lives at slot c ^ ((r >> 1) & 7)  (conflict-free ds_read_b128 for the
+// 32x32x16 operand pattern: lanes 0-31 = rows, lane >> 5 = neighbouring chunk; the attention kernels' K tiles use the same image)
+__device__ __forceinline__ int lds_off64(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// 64-byte LDS rows (32 bf16): slot = chunk ^ h(row >> 2), h = (0, 2, 3, 1)
+__device__ __forceinline__ int swz32(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ swz32(row)) << 4); }
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Feed-forward: out = x + W2 (value * gelu(gate)) + b2, [value | gate] = W1 LayerNorm(x) + b1      (lvdm/modules/attention.py:253,431-458)
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int FF_C = 320, FF_BM = 128, FF_KS = FF_C / 16, FF_NSLAB = FF_C / 64, FF_HID = 4 * FF_C, FF_NCH = FF_HID / 32, FF_NF = FF_C / 32;
+constexpr int FF_W1_STAGE = 64 * FF_C * 2;            // one chunk of W1: 64 interleaved (value, gate) rows x C   = 40 KiB  [slab][64 rows][128 B]
+constexpr int FF_W2_SLOT = FF_C * 32 * 2;             // one chunk of W2: C rows x 32 hidden units                = 20 KiB  [C rows][64 B]
+constexpr int FF_W1_OFF = 0, FF_W2_OFF = 2 * FF_W1_STAGE;
+constexpr int FF_XS_OFF = FF_W1_STAGE;                // the fp16 rows of the prologue: W1 stage 1 + W2 slots 0, 1 (80 KiB)
+constexpr int FF_LDS = FF_W2_OFF + 3 * FF_W2_SLOT;    // 140 KiB
+constexpr int FF_PITCH = FF_C * 2 + 16;               // row pitch of the epilogue's tile image
+static_assert(FF_XS_OFF + FF_BM * FF_C * 2 <= FF_LDS && FF_BM * FF_PITCH <= FF_LDS, "LDS map");
+
+template <int OUT_KIND>
+__global__ __launch_bounds__(256, 1) void ff_fused_kernel(const CcvFF p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar for the compiler: LDS-DMA destinations (M0) stay in SGPRs
+    const int r = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * FF_BM;
+
+    // ---- weight DMA (buffer descriptors: per-lane offset fixed for the kernel, chunk / slab / row group ride in the scalar offset) ----
+    const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w1), 0, 2 * FF_HID * FF_C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w2p), 0, FF_C * FF_HID * 2, 0x00020000);
+    const int lrow8 = lane >> 3, lch8 = lane & 7;
+    const int row_a = 8 * wave + lrow8;                                             // W1 chunk rows 8 (wave + 4 g) + lrow8, g = 0, 1 (same swizzle term)
+    const int voff1 = (row_a * FF_C + ((lch8 ^ ((row_a >> 1) & 7)) << 3)) * 2;
+    const int lrow4 = lane >> 2, slot4 = lane & 3;
+    const int row_b = 16 * wave + lrow4;                                            // W2 rows 16 (wave + 4 q) + lrow4, q = 0 .. 4 (same swizzle term)
+    const int voff2 = (row_b * FF_HID + ((slot4 ^ swz32(row_b)) << 3)) * 2;
+    auto issue_w1 = [&](int c, int stage) __attribute__((always_inline)) {        // 10 pieces of 8 rows x 128 B per wave
+#pragma unroll
+        for (int q = 0; q < FF_NSLAB; ++q)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (lptr_t*)(smem + FF_W1_OFF + stage * FF_W1_STAGE + (q * 64 + 8 * (wave + 4 * g)) * 128), 16,
+                                                         voff1, c * (64 * FF_C * 2) + q * 128 + g * (32 * FF_C * 2), 0, 0);
+    };
+    auto issue_w2 = [&](int c, int slot) __attribute__((always_inline)) {         // 5 pieces of 16 rows x 64 B per wave
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (lptr_t*)(smem + FF_W2_OFF + slot * FF_W2_SLOT + 16 * (wave + 4 * q) * 64), 16,
+                                                     voff2, c * 64 + q * (64 * FF_HID * 2), 0, 0);
+    };
+
+    // ---- prologue: W1 chunk 0 flies into stage 0 while the tile's fp16 rows are staged (whole 128-byte lines) and normalised ----
+    issue_w1(0, 0);
+    {
+        const uint16_t* X = static_cast<const uint16_t*>(p.x);
+#pragma unroll
+        for (int q = 0; q < FF_NSLAB * (FF_BM / 8) / 4; ++q) {
+            const int pid = wave + 4 * q, slab = pid >> 4, rg = pid & 15;
+            const int rr = 8 * rg + lrow8;
+            const uint16_t* src = X + (long)(m0 + rr) * p.ldx + slab * 64 + ((lch8 ^ ((rr >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(smem + FF_XS_OFF + (slab * FF_BM + 8 * rg) * 128), 16, 0, 0);
+        }
+    }
+    wait_vm0();
+    __syncthreads();
+
+    // activation fragments (B operand): row 32 wave + r, k = 16 ks + 8 hh .. + 7, LayerNorm applied on the way (fp32 statistics over
+    // the row: the two lanes r / r + 32 hold its two halves)
+    bf16x8 fa[FF_KS];
+    {
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+        const int row = 32 * wave + r;
+        auto frag = [&](int ks) {
+            return *reinterpret_cast<const f16x8*>(smem + FF_XS_OFF + (ks >> 2) * (FF_BM * 128) + lds_off64(row, 2 * (ks & 3) + hh));
+        };
+        float a = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < FF_KS; ++ks) {
+            const f16x8 h = frag(ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += (float)h[e];
+        }
+        const float mean = (a + __shfl_xor(a, 32, 64)) * (1.0f / (float)FF_C);
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < FF_KS; ++ks) {
+            const f16x8 h = frag(ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)h[e] - mean; q += d * d; }
+        }
+        const float rstd = rsqrtf((q + __shfl_xor(q, 32, 64)) * (1.0f / (float)FF_C) + p.ln_eps);
+        static_for<0, FF_KS, 1>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            const int k0 = 16 * ks + 8 * hh;
+            const float4 g0 = *reinterpret_cast<const float4*>(p.ln_gamma + k0), g1 = *reinterpret_cast<const float4*>(p.ln_gamma + k0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.ln_beta + k0), b1 = *reinterpret_cast<const float4*>(p.ln_beta + k0 + 4);
+            const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const f16x8 h = frag(ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[ks][e] = (__bf16)(((float)h[e] - mean) * rstd * gm[e] + bt[e]);
+        });
+    }
+#pragma unroll
+    for (int ks = 0; ks < FF_KS; ++ks) asm volatile("" ::"v"(fa[ks]));      // every fragment read (and the gamma / beta loads) retired here
+    lds_barrier();                                                           // all waves are done with the staged rows
+
+    f32x16 out[FF_NF];
+#pragma unroll
+    for (int nf = 0; nf < FF_NF; ++nf)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[nf][i] = 0.f;
+
+    // b1 of a chunk, in the accumulator layout (register 4 g4 + i of fragment f = feature 64 c + 32 f + 8 g4 + 4 hh + i): ordinary
+    // loads issued one chunk ahead (their wait coincides with the drain at the top of the next step; an LDS copy of b1 read from
+    // C++ made hipcc put an s_waitcnt vmcnt(0) -- the weight DMA just issued -- in front of the read)
+    f32x16 bz[2];
+    auto load_bias = [&](int c) __attribute__((always_inline)) {
+        const float* sb = p.b1 + c * 64 + 4 * hh;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bv = *reinterpret_cast<const float4*>(sb + 32 * f + 8 * g4);
+                bz[f][4 * g4] = bv.x; bz[f][4 * g4 + 1] = bv.y; bz[f][4 * g4 + 2] = bv.z; bz[f][4 * g4 + 3] = bv.w;
+            }
+    };
+
+    // One step of the software pipeline: U(c) and G(c - 1) written as ONE k-loop, then D(c - 1).
+    //   U(c)     [value | gate] of chunk c for this wave's 32 rows: two 32-column fragments (16 values + their 16 gates each) x 20
+    //            k-steps of v_mfma_f32_32x32x16_bf16, accumulators seeded with the bias, W1 fragments PF k-steps ahead of their use
+    //            (with ONE wave per SIMD nothing else covers the LDS latency: a read issued one MFMA ahead made every MFMA wait ~100
+    //            cycles for its operands, 7400 cycles per chunk); a lane (row r, half hh) ends with register 4 g4 + i = feature
+    //            8 g4 + 4 hh + i: g4 = 0, 1 the values of hidden units 16 f + 8 g4 + 4 hh + i, g4 = 2, 3 their gates;
+    //   G(c - 1) value * gelu(gate) of the previous chunk, one hidden unit per k-step, in the shadow of U's MFMAs (written in the order
+    //            wanted: left to itself hipcc clumps the ~200 vector instructions behind the last MFMA); the 8 units a lane holds per
+    //            fragment ARE the B fragment of k-step f of the down-projection (k order 0-3, 8-11, 4-7, 12-15: W2 is stored that way);
+    //   D(c - 1) out^T[n][m] += W2[n][chunk] . h[m][chunk]: 10 fragments of 32 output features x 2 k-steps.
+    // Tried and measured slower (profiles/r04_ff_fused_notes.txt): D(c - 2) interleaved into the same k-loop (three streams: hipcc's
+    // schedule degenerates, 110 -> 123 us), the next chunk's DMA pieces issued between the MFMAs (the builtins split the scheduling
+    // region; spills), sched_group_barrier patterns (the fragment prefetch collapses to lgkmcnt(0)).
+    bf16x8 hf[2];
+    auto step = [&](int c, auto DO_UP, auto DO_GATE, bool more, f32x16 (&cur)[2], const f32x16 (&prev)[2]) __attribute__((always_inline)) {
+        constexpr bool do_up = decltype(DO_UP)::value, do_gate = decltype(DO_GATE)::value;
+        const unsigned char* sW1 = smem + FF_W1_OFF + (c & 1) * FF_W1_STAGE;
+        constexpr int PF = 4;               // W1 fragment pairs in flight ahead of their MFMAs
+        bf16x8 wf[PF][2];
+        auto fetch1 = [&](auto Q, bf16x8 (&dst)[2]) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            const int ch = 2 * (ks & 3) + hh;
+            dst[0] = *reinterpret_cast<const bf16x8*>(sW1 + (ks >> 2) * (64 * 128) + lds_off64(r, ch));
+            dst[1] = *reinterpret_cast<const bf16x8*>(sW1 + (ks >> 2) * (64 * 128) + lds_off64(32 + r, ch));
+        };
+        if constexpr (do_up) {
+            cur[0] = bz[0];
+            cur[1] = bz[1];
+            if (more) load_bias(c + 1);
+            static_for<0, PF, 1>([&](auto Q) __attribute__((always_inline)) { fetch1(Q, wf[decltype(Q)::value]); });
+        }
+        static_for<0, FF_KS, 1>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int ks = decltype(Q)::value;
+            if constexpr (do_up) {
+                const bf16x8 w0 = wf[ks % PF][0], w1 = wf[ks % PF][1];
+                if constexpr (ks + PF < FF_KS) fetch1(std::integral_constant<int, ks + PF>{}, wf[ks % PF]);
+                cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, fa[ks], cur[0], 0, 0, 0);
+                cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, fa[ks], cur[1], 0, 0, 0);
+            }
+            if constexpr (do_gate && ks < 16) {
+                constexpr int f = ks >> 3, e = ks & 7;
+                hf[f][e] = (__bf16)(prev[f][e] * gelu_erf_f(prev[f][8 + e]));
+            }
+        });
+        if constexpr (do_gate) {
+            const unsigned char* sW2 = smem + FF_W2_OFF + ((c + 2) % 3) * FF_W2_SLOT;       // chunk c - 1
+            constexpr int PD = 3;               // W2 fragment pairs in flight ahead of their MFMAs
+            bf16x8 wd[PD][2];
+            auto fetch2 = [&](auto N, bf16x8 (&dst)[2]) __attribute__((always_inline)) {
+                constexpr int nf = decltype(N)::value;
+                dst[0] = *reinterpret_cast<const bf16x8*>(sW2 + lds_off32(32 * nf + r, hh));
+                dst[1] = *reinterpret_cast<const bf16x8*>(sW2 + lds_off32(32 * nf + r, 2 + hh));
+            };
+            static_for<0, PD, 1>([&](auto N) __attribute__((always_inline)) { fetch2(N, wd[decltype(N)::value]); });
+            static_for<0, FF_NF, 1>([&](auto N) __attribute__((always_inline)) {
+                constexpr int nf = decltype(N)::value;
+                const bf16x8 w0 = wd[nf % PD][0], w1 = wd[nf % PD][1];
+                if constexpr (nf + PD < FF_NF) fetch2(std::integral_constant<int, nf + PD>{}, wd[nf % PD]);
+                out[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, hf[0], out[nf], 0, 0, 0);
+                out[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, hf[1], out[nf], 0, 0, 0);
+            });
+        }
+    };
+    // Rings: W1 two stages (stage (c + 1) & 1 was last read by U(c - 1)), W2 three slots (slot (c + 1) % 3 was last read by D(c - 2), in
+    // step c - 1): every reuse is separated from the last read by the barrier at the top of a step; a step's weights were issued one
+    // step earlier.
+    auto top = [&](int c, bool more) __attribute__((always_inline)) {
+        wait_vm0();
+        lds_barrier();
+        if (more) {
+            issue_w1(c + 1, (c + 1) & 1);
+            issue_w2(c + 1, (c + 1) % 3);
+        }
+    };
+    const std::true_type T{};
+    const std::false_type F{};
+    f32x16 accA[2], accB[2];
+    load_bias(0);
+    issue_w1(1, 1);
+    issue_w2(0, 0);
+    issue_w2(1, 1);
+    step(0, T, F, true, accA, accB);                              // U(0)
+    for (int c = 1; c + 1 < FF_NCH; c += 2) {                     // c = 1 .. 38 in pairs: the accumulator sets swap roles
+        top(c, true);
+        step(c, T, T, true, accB, accA);                          // U(c) G(c - 1) D(c - 1), c odd
+        top(c + 1, true);
+        step(c + 1, T, T, true, accA, accB);
+    }
+    top(FF_NCH - 1, false);
+    step(FF_NCH - 1, T, T, false, accB, accA);                    // U(39) G(38) D(38)
+    step(FF_NCH, F, T, false, accA, accB);                        // G(39) D(39): W2 chunk 39 landed before the last barrier
+
+    // ---- epilogue: + b2 + x (fp16, fp32 add, ONE rounding), whole rows through LDS both ways ---------------------------------------
+    lds_barrier();                                       // every wave is past its last weight-fragment read
+    {
+        const uint16_t* X = static_cast<const uint16_t*>(p.x);
+        for (int idx = tid; idx < FF_BM * (FF_C / 8); idx += 256) {
+            const int row = idx / (FF_C / 8), ch = idx - row * (FF_C / 8);
+            *reinterpret_cast<uint4*>(smem + row * FF_PITCH + ch * 16) = *reinterpret_cast<const uint4*>(X + (long)(m0 + row) * p.ldx + ch * 8);
+        }
+    }
+    __syncthreads();
+    {
+        unsigned char* srow = smem + (32 * wave + r) * FF_PITCH;
+        static_for<0, FF_NF, 1>([&](auto N) __attribute__((always_inline)) {
+            constexpr int nf = decltype(N)::value;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = 32 * nf + 8 * g4 + 4 * hh;
+                const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+                uint2* slot = reinterpret_cast<uint2*>(srow + n * 2);
+                const uint2 rv = *slot;
+                const float2 ra = ccv_unpack_f16x2(rv.x), rb = ccv_unpack_f16x2(rv.y);
+                const float o0 = out[nf][4 * g4] + bv.x + ra.x, o1 = out[nf][4 * g4 + 1] + bv.y + ra.y;
+                const float o2 = out[nf][4 * g4 + 2] + bv.z + rb.x, o3 = out[nf][4 * g4 + 3] + bv.w + rb.y;
+                *slot = OUT_KIND == 2 ? make_uint2(ccv_pack_f16x2(o0, o1), ccv_pack_f16x2(o2, o3)) : make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            }
+        });
+    }
+    __syncthreads();
+    {
+        uint16_t* O = static_cast<uint16_t*>(p.out);
+        for (int idx = tid; idx < FF_BM * (FF_C / 8); idx += 256) {
+            const int row = idx / (FF_C / 8), ch = idx - row * (FF_C / 8);
+            *reinterpret_cast<uint4*>(O + (long)(m0 + row) * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(smem + row * FF_PITCH + ch * 16);
+        }
+    }
+#endif
+}
+
+inline bool ff_fits(const CcvFF& p) {
+    static const bool on = [] { const char* e = getenv("CCV_FF_FUSED"); return !(e && e[0] == '0'); }();   // A/B aid
+    return on && p.C == FF_C && p.M > 0 && p.M % FF_BM == 0 && p.ldx >= FF_C && p.ldo >= FF_C && p.ldx % 8 == 0 && p.ldo % 8 == 0 &&
+           (p.out_kind == 0 || p.out_kind == 2) && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(p.w1) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w2p) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.b1) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(p.b2) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.ln_gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.ln_beta) & 15) == 0;
+}
+
+template <int OUT_KIND>
+int launch_ff(const CcvFF& p, hipStream_t st) {
+    auto kern = ff_fused_kernel<OUT_KIND>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.M / FF_BM), dim3(256), FF_LDS, st, p);
+    CCV_LAUNCH_CHECK("ccv_ff_fused");
+    return CCV_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t ccv_ff_fusable(const CcvFF* p) {
+    return (p != nullptr && p->x && p->w1 && p->b1 && p->w2p && p->b2 && p->out && p->ln_gamma && p->ln_beta && ff_fits(*p)) ? 1 : 0;
+}
+
+extern "C" int ccv_ff_fused(const CcvFF* pp, void* stream) {
+    CCV_REQUIRE(pp != nullptr, CCV_EINVAL, "ccv_ff_fused: null params");
+    const CcvFF& p = *pp;
+    CCV_REQUIRE(p.x && p.w1 && p.b1 && p.w2p && p.b2 && p.out && p.ln_gamma && p.ln_beta, CCV_EINVAL, "ccv_ff_fused: null operand");
+    CCV_REQUIRE(ff_fits(p), CCV_ESHAPE, "ccv_ff_fused: built for C = 320, M %% 128 == 0, 16-byte aligned operands, fp16 / bf16 output "
+                "(got C = %d, M = %d, ldx = %d, ldo = %d, out_kind = %d): ask ccv_ff_fusable() first", p.C, p.M, p.ldx, p.ldo, p.out_kind);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return p.out_kind == 2 ? launch_ff<2>(p, st) : launch_ff<0>(p, st);
+}

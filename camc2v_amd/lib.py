@@ -29,6 +29,14 @@ class CcvGemm(C.Structure):
     ]
 
 
+class CcvFF(C.Structure):
+    _fields_ = [
+        ("x", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32),
+        ("w1", vp), ("b1", vp), ("w2p", vp), ("b2", vp), ("out", vp),
+        ("M", i32), ("C", i32), ("ldx", i32), ("ldo", i32), ("out_kind", i32),
+    ]
+
+
 class CcvAttn(C.Structure):
     _fields_ = [
         ("q", vp), ("k", vp), ("v", vp), ("o", vp),
@@ -63,6 +71,8 @@ SIGNATURES = {
     "ccv_gemm_plan": (i32, [C.POINTER(CcvGemm), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccv_gemm_ln_fusable": (i32, [C.POINTER(CcvGemm)]),
     "ccv_gemm_gn_slots": (i32, [C.POINTER(CcvGemm), i32]),
+    "ccv_ff_fusable": (i32, [C.POINTER(CcvFF)]),
+    "ccv_ff_fused": (i32, [C.POINTER(CcvFF), vp]),
     "ccv_groupnorm_apply_parts": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),

@@ -10,7 +10,7 @@ import threading
 
 import torch
 
-from .lib import CcvAttn, CcvError, CcvGemm, check, lib
+from .lib import CcvAttn, CcvError, CcvFF, CcvGemm, check, lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -218,6 +218,58 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         e1.record()
         probe.append((e0, e1, 2.0 * M * N * K * taps))
     return (out, stats) if gn_rows else out
+
+
+def _ff_params(x, gamma, beta, eps, w1, b1, w2p, b2, out):
+    p = CcvFF()
+    p.x, p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(x), _ptr(gamma), _ptr(beta), float(eps)
+    p.w1, p.b1, p.w2p, p.b2, p.out = _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2), _ptr(out)
+    p.M, p.C, p.ldx, p.ldo = x.shape[0], x.shape[1], x.stride(0), out.stride(0)
+    p.out_kind = _KIND[out.dtype]
+    return p
+
+
+def ff_fusable(x, w1, w2p):
+    """Whether ``ff_fused`` takes this feed-forward (csrc/ccv_fused.hip: the fp16 stream of the 32x32-latent blocks, C = 320)."""
+    if w2p is None or x.dtype != F16 or x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda:
+        return False
+    C_ = x.shape[1]
+    if tuple(w1.shape) != (8 * C_, C_) or tuple(w2p.shape) != (C_, 4 * C_):
+        return False
+    return bool(lib().ccv_ff_fusable(C.byref(_ff_params(x, x, x, 0.0, w1, x, w2p, x, x))))
+
+
+FF_PROBE = None     # a list: ff_fused() appends (start event, end event, flops) per call (eager mode only; bench.py's gemm_family)
+
+
+def ff_fused(x, gamma, beta, eps, w1, b1, w2p, b2, *, out=None, out_dtype=None):
+    """out = x + Linear_2(value * gelu(gate)), [value | gate] = Linear_1(LayerNorm(x)) in ONE launch (include/ccv.h, ccv_ff_fused;
+    reference lvdm/modules/attention.py:253,431-458).  x: the fp16 stream [M, C]; w1 / b1: GEGLU-interleaved (pack.interleave_geglu);
+    w2p: pack.permute_k16_for_acc_operand(W2).  out: fp16 (default: a new tensor; may be x itself) or bf16."""
+    _dev(x, gamma, beta, w1, b1, w2p, b2, out)
+    if x.dtype != F16 or x.dim() != 2 or x.stride(1) != 1:
+        raise CcvError("ff_fused: x must be the fp16 stream [M, C] with a contiguous last dim")
+    M, C_ = x.shape
+    if w1.dtype != BF16 or w2p.dtype != BF16 or not w1.is_contiguous() or not w2p.is_contiguous() or \
+            tuple(w1.shape) != (8 * C_, C_) or tuple(w2p.shape) != (C_, 4 * C_):
+        raise CcvError(f"ff_fused: w1 must be contiguous bf16 [8C, C] and w2p [C, 4C] for C = {C_}")
+    for t, n in ((gamma, C_), (beta, C_), (b1, 8 * C_), (b2, C_)):
+        if t.dtype != F32 or not t.is_contiguous() or t.numel() < n:
+            raise CcvError("ff_fused: gamma / beta / b1 / b2 must be contiguous fp32 vectors of C / C / 8C / C elements")
+    if out is None:
+        out = torch.empty((M, C_), dtype=out_dtype or F16, device=x.device)
+    if out.dtype not in (F16, BF16) or out.dim() != 2 or out.shape[0] < M or out.shape[1] < C_ or out.stride(1) != 1:
+        raise CcvError(f"ff_fused: out must be fp16 / bf16 [>= {M}, >= {C_}]")
+    p = _ff_params(x, gamma, beta, eps, w1, b1, w2p, b2, out)
+    probe = FF_PROBE
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().ccv_ff_fused(C.byref(p), _stream()), "ccv_ff_fused")
+    if probe is not None:
+        e1.record()
+        probe.append((e0, e1, 2.0 * M * C_ * 12 * C_))
+    return out
 
 
 # tests / tuning tools: when TRACK_GEMM_PLAN is set, LAST_GEMM_PLAN = (ring tile index or -1, split-K) of the last call

@@ -53,3 +53,12 @@ def interleave_geglu(w, b):
     bv, bg = b[:inner].reshape(inner // 16, 16), b[inner:].reshape(inner // 16, 16)
     bp = torch.stack([bv, bg], dim=1).reshape(2 * inner)
     return wp.to(BF16).contiguous(), bp.float().contiguous()
+
+
+def permute_k16_for_acc_operand(w):
+    """[N, K] (K % 16 == 0) -> bf16 [N, K] with the columns of every 16-column group in the order 0-3, 8-11, 4-7, 12-15: the k
+    order in which a 32x32 MFMA accumulator hands its rows to the next MFMA as an operand (csrc/ccv_fused.hip): the weight of the
+    product that consumes an in-register intermediate is stored this way, so the intermediate needs no lane movement."""
+    n, k = w.shape
+    assert k % 16 == 0
+    return w.reshape(n, k // 16, 4, 4)[:, :, [0, 2, 1, 3], :].reshape(n, k).to(BF16).contiguous()

@@ -36,6 +36,8 @@ FUSE_CAMERA_PROJECTIONS = __import__("os").environ.get("CCV_FUSE_CAM", "1") != "
 # CCV_ATTN_FP8=1: the masked epipolar attention of feature maps with >= FP8_EPIPOLAR_MIN_TOKENS tokens runs the e4m3 kernel
 FP8_EPIPOLAR = __import__("os").environ.get("CCV_ATTN_FP8", "0") == "1"
 FP8_EPIPOLAR_MIN_TOKENS = 2048
+# A/B aid: CCV_FUSE_FF=0 runs every feed-forward as LayerNorm + two GEMMs (the one-launch form exists for C = 320: csrc/ccv_fused.hip)
+FUSE_FF = __import__("os").environ.get("CCV_FUSE_FF", "1") != "0"
 TEXT_LEN = 77  # CrossAttention.text_context_len (reference attention.py:49)
 # The residual stream between layers: fp16 -- what the reference itself carries between blocks under its fp16 autocast
 # (main/trainer.py:193: conv / linear outputs are fp16, only the norms compute in fp32) -- with fp32 arithmetic inside every
@@ -285,12 +287,21 @@ class FeedForward(nn.Module, _Prepared):
 
     def _pack(self):
         w, b = pack.interleave_geglu(self.net[0].proj.weight, self.net[0].proj.bias)
-        return dict(w1=w, b1=b, w2=pack.pack_linear(self.net[2].weight), b2=_dev_f32(self.net[2].bias))
+        pk = dict(w1=w, b1=b, w2=pack.pack_linear(self.net[2].weight), b2=_dev_f32(self.net[2].bias))
+        if self.net[2].in_features == 4 * self.net[2].out_features == 4 * self.net[0].proj.in_features and self.net[2].out_features == 320:
+            pk["w2p"] = pack.permute_k16_for_acc_operand(self.net[2].weight)     # operand of the one-launch form (ops.ff_fused)
+        return pk
 
     def run(self, n, stream, final=False):
-        """final: the stream is only read as a GEMM operand afterwards (proj_out), so the sum is handed back
-        rounded to bf16 (the rounding the operand load would apply anyway) instead of updating the fp32 stream."""
+        """n: LayerNorm of the stream (an ops.LazyLN, or the bf16 rows).  final: the stream is only read as a GEMM operand afterwards
+        (proj_out), so the sum is handed back rounded to bf16 (the rounding the operand load would apply anyway) instead of updating
+        the stream."""
         pk = self._pk()
+        if FUSE_FF and isinstance(n, ops.LazyLN) and n._t is None and n.x is stream and ops.ff_fusable(stream, pk["w1"], pk.get("w2p")):
+            # LayerNorm -> GEGLU up -> down -> + x as ONE launch: the [M, 4C] hidden activation never reaches memory
+            if final:
+                return ops.ff_fused(stream, n.gamma, n.beta, n.eps, pk["w1"], pk["b1"], pk["w2p"], pk["b2"], out_dtype=ops.BF16)
+            return ops.ff_fused(stream, n.gamma, n.beta, n.eps, pk["w1"], pk["b1"], pk["w2p"], pk["b2"], out=stream)
         hidden = ops.gemm(n, pk["w1"], bias=pk["b1"], geglu=True)
         if final:
             return ops.gemm(hidden, pk["w2"], bias=pk["b2"], residual=stream)

@@ -149,6 +149,35 @@ int32_t ccv_gemm_ln_fusable(const CcvGemm* p);
 int32_t ccv_gemm_gn_slots(const CcvGemm* p, int32_t rows_per_instance);
 
 /* ------------------------------------------------------------------------------------
+ * ccv_ff_fused: one launch for a whole gated feed-forward block of a transformer,
+ *     out = x + Linear_2( value * gelu_erf(gate) ) ,  [value | gate] = Linear_1( LayerNorm(x) )
+ * Replaces `x = self.ff(self.norm3(x)) + x` (lvdm/modules/attention.py:253) = nn.LayerNorm (:234) + GEGLU (:431-438) +
+ * FeedForward (:441-458) -- today ccv_layernorm + two ccv_gemm launches with the [M, 4C] bf16 hidden tensor written to and
+ * re-read from HBM in between (84 MB each way per block at 32x32 latents).  Here one 4-wave workgroup owns 128 token rows:
+ * the rows are normalised once into MFMA operand registers, the hidden units are produced 32 at a time (v_mfma_f32_32x32x16_bf16
+ * against a 64-column strip of W1 streamed through LDS), gated in registers, and -- the accumulator layout of one product being the
+ * operand layout of the next -- multiplied straight into the resident [128, C] output accumulators against the matching
+ * 32-column chunk of W2: the hidden activation never exists in memory, not even in LDS.
+ *   x      : [M, ldx] fp16 residual stream (LayerNorm input and residual), M % 128 == 0
+ *   w1, b1 : [8C, C] bf16 / [8C] fp32, value / gate rows interleaved in 16-row blocks (the layout ccv_gemm's geglu takes)
+ *   w2p    : [C, 4C] bf16 with the columns of every 16-column group in the order 0-3, 8-11, 4-7, 12-15 (the k order in which a
+ *            32x32 accumulator hands its rows to the next MFMA); b2 [C] fp32
+ *   out    : [M, ldo] fp16 (out_kind 2; may alias x) or bf16 (out_kind 0)
+ * Only C = 320 (the 32x32-latent blocks) is built: ccv_ff_fusable() says whether a problem is taken (0: run the three launches).
+ * ------------------------------------------------------------------------------------ */
+typedef struct CcvFF {
+    const void* x;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const uint16_t* w1; const float* b1;
+    const uint16_t* w2p; const float* b2;
+    void* out;
+    int32_t M, C, ldx, ldo;
+    int32_t out_kind;       /* 0: bf16, 2: fp16 */
+} CcvFF;
+int32_t ccv_ff_fusable(const CcvFF* p);
+int ccv_ff_fused(const CcvFF* p, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * ccv_attn_fwd: O = softmax(Q K^T * scale [+ mask]) V, head dim 64, bf16 MFMA, fp32 online
  * softmax; optionally a second key/value set attended separately and added with a gate.
  *
