@@ -15,6 +15,7 @@
 // leading, always-visible K/V segment.  An optional second context (image tokens) is a second
 // softmax pass over the same Q tile, added with a gate.
 #include <atomic>
+#include <type_traits>
 
 #include "ccv_common.h"
 
@@ -694,6 +695,7 @@ struct SparseArgs {
     int32_t B, inner, H, Lq, Lk, nreg, perm_hw, perm_w;
     float scale;
     int32_t slot, use_xcd_queues;
+    const int32_t* wg_order; int32_t wg_order_bs;   // attn_shared_kernel: items (groups of NW * 32 queries) longest first
 };
 
 __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p) {
@@ -1005,6 +1007,332 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
 }
 
 // =================================================================================================
+// attn_shared_kernel<NW, S> (round 4): the same masked attention with the K / V blocks SHARED by a workgroup.
+// attn_sparse_kernel's waves each stream their own copy of every 32-key block they need: 8 KiB of DMA per 16 MFMAs, 12x the
+// algorithmic bytes per launch, two thirds of it missing the XCD's L2.  Patch-ordered neighbours need almost the same
+// blocks (benchmark masks, 32x32 latents: a 64-query group needs 173 of the 512 blocks, the 256 queries of four
+// neighbouring groups 254 together), so here a workgroup of NW waves owns NW * 32 consecutive queries -- ONE 4x8-pixel
+// patch per wave -- and walks the union of its groups' bitmaps (the OR of their wave_bits rows).  Every block of that
+// union is staged ONCE per workgroup into an S-deep ring: each wave issues 8 / NW of its eight 1 KiB pieces (+ the mask words
+// of its own 32 queries), so a wave issues 2-3 vector-memory operations per block instead of 9.  One s_barrier per block:
+//     wait for my own pieces of block i (counted vmcnt: blocks i+1 .. i+S-2 stay in flight) -> s_barrier (everybody's pieces
+//     of block i have landed AND everybody has finished block i-1) -> issue block i+S-1 into the stage of block i-1
+//     -> multiply block i if one of my 32 queries sees a key of it (ballot over the mask words), else go on.
+// A wave holds 32 queries instead of 64: half the accumulators (<= 128 registers per lane: four waves per SIMD instead of
+// two), and a half without a visible key costs nothing instead of a full softmax (attn_sparse_kernel multiplies both halves
+// of every block it visits: 346 half-blocks per group against the 290 needed).  Math per half-block is attn_sparse_kernel's:
+// seeded S^T = K Q^T, in-lane softmax, O^T += V^T P^T.  Items (batch-head slice, query group) come from the same persistent
+// queue, longest first by p.wg_order (ccv_attn_group_order_merged).
+// =================================================================================================
+template <int NW, int S>
+__global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(S >= 3 && S <= 6, "ring depth");
+    constexpr int RING = S * 8192, MWB = NW * S * 256;
+    constexpr int PP = 8 / NW;          // K / V pieces per wave and block
+    constexpr int P = PP + 1;           // + the wave's mask words: vector-memory operations per wave and block
+    constexpr int GQ = NW * 32;         // queries per item
+    constexpr int DONE = 0x7fffffff;
+    __shared__ __attribute__((aligned(256))) unsigned char sm[RING + MWB + 256 + 16];   // ring | mask words [wave][stage][64] | seed table | item
+    static_assert((RING + MWB) % 256 == 0, "seed table offset must keep the low 8 address bits clear");
+    float* seed_lut = reinterpret_cast<float*>(sm + RING + MWB);
+    volatile unsigned int* item_word = reinterpret_cast<volatile unsigned int*>(sm + RING + MWB + 256);
+    const int tid = threadIdx.x;
+    if (tid < 64) seed_lut[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 0.f : NEG_INF;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const float sl2 = p.scale * 1.4426950408889634f;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
+    unsigned char* mwring = sm + RING + wave * (S * 256);
+    const bool has_reg = p.kreg != nullptr && p.nreg > 0;
+    const int ngroups = (p.Lq + GQ - 1) / GQ;
+    const int ngroups64 = (p.Lq + 63) >> 6;
+    const int nbh = p.B * p.H;
+    const int k_ls32 = (int)p.k_ls, v_ls32 = (int)p.v_ls;
+    const int ppr_ = p.perm_w >> 3;
+    const bool perm_pow2 = p.perm_w && (p.perm_hw & (p.perm_hw - 1)) == 0 && (ppr_ & (ppr_ - 1)) == 0;
+    const int sh_hw = perm_pow2 ? __builtin_ctz(p.perm_hw) : 0, sh_ppr = perm_pow2 ? __builtin_ctz(ppr_) : 0;
+    const long qitems = (long)nbh * ngroups;
+    const int lr8 = lane >> 3, pc = lane & 7;
+    // per-lane LDS addresses of stage 0 (see compute): seed table, the four K fragments, the two V^T read bases (read_vt_block's layout)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(sm);
+    const uint32_t lut_addr = lds0 + RING + MWB;
+    uint32_t ka[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ka[s] = lds0 + r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
+    uint32_t va0, va1;
+    {
+        const int li = lane & 15, g = (lane >> 4) & 1;
+        const int row0 = 4 * hh + (li >> 2);
+        const int x = ((row0 >> 1) & 1) << 6;
+        const int c = (16 * g + 4 * (li & 3)) * 2;
+        va0 = lds0 + row0 * 128 + c + x;
+        va1 = lds0 + row0 * 128 + c + 64 - x;
+    }
+
+  for (;;) {
+    __syncthreads();   // everybody is done with the previous item: the ring, the mask words and the item word are free
+    if (tid == 0) *item_word = atomicAdd(p.queue_counters ? p.queue_counters : &g_sparse_ctr[p.slot][0], 1u);
+    __syncthreads();
+    const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*item_word);
+    if (item >= qitems) break;
+    const int rank = (int)(item / nbh), bh = (int)(item % nbh);
+    const int head = bh % p.H, b = bh / p.H;
+    const int mb = b % p.mask_nb;
+    const int qg = p.wg_order ? p.wg_order[(long)mb * p.wg_order_bs + rank] : rank;
+    const long bo = b / p.inner, bi = b % p.inner;
+    const int q0w = qg * GQ + 32 * wave;          // this wave's 32 queries
+    const bool wave_active = q0w < p.Lq;
+
+    bf16x8 qf[4];
+    {
+        const int qi = min(q0w + r, p.Lq - 1);
+        const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)ccv_patch_row(qi, p.perm_hw, p.perm_w) * p.q_ls + head * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    const uint16_t* kmain = p.k + bo * p.k_bso + bi * p.k_bsi + head * 64;
+    const uint16_t* vmain = p.v + bo * p.v_bso + bi * p.v_bsi + head * 64;
+
+    // ---- block schedule (identical in every wave): -1 = register tokens, then the set bits of the OR of the item's bitmap rows ----
+    uint32_t my_word = 0u;
+    {
+        const uint32_t* wrow = p.wave_bits + (long)mb * p.wave_bs;
+#pragma unroll
+        for (int j = 0; j < NW / 2; ++j) {
+            const int g64 = qg * (NW / 2) + j;
+            if (g64 < ngroups64 && lane < p.wave_words) my_word |= wrow[(long)g64 * p.wave_words + lane];
+        }
+    }
+    int widx = -1;
+    uint32_t cbits = 0;
+    bool reg_pending = has_reg;
+    auto next_block = [&]() -> int {
+        if (reg_pending) { reg_pending = false; return -1; }
+        while (cbits == 0) {
+            if (++widx >= p.wave_words) { widx = p.wave_words; return DONE; }
+            cbits = (uint32_t)__builtin_amdgcn_readlane((int)my_word, widx);
+        }
+        const int bit = __builtin_ctz(cbits);
+        cbits &= cbits - 1;
+        return widx * 32 + bit;
+    };
+
+    // this wave's pieces of a block: piece id = wave * PP + t; ids 0-3 are the four 8-row pieces of K, 4-7 those of V
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kmain), 0, ((p.Lk - 1) * k_ls32 + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vmain), 0, ((p.Lk - 1) * v_ls32 + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.mask_bits + (long)mb * p.mask_bs), 0, p.Lq * p.mask_words * 4, 0x00020000);
+    int poff32[PP];
+#pragma unroll
+    for (int t = 0; t < PP; ++t) {
+        const int pid = wave * PP + t, j = pid & 3;
+        const bool isk = pid < 4;
+        const int rowin = 8 * j + lr8;
+        const long step = p.perm_w ? (long)j * p.perm_w + lr8 : (long)rowin;
+        const int swz = isk ? ((pc ^ ((rowin >> 1) & 7)) << 3) : ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
+        poff32[t] = (int)(step * (isk ? p.k_ls : p.v_ls) + swz) * 2;
+    }
+    const int moff32 = min(q0w + r, p.Lq - 1) * p.mask_words * 4;   // both half-waves fetch the 32 words (lane l <-> query q0w + (l & 31))
+
+    auto issue = [&](int blk, int stage) __attribute__((always_inline)) {
+        unsigned char* sK = sm + stage * 8192;
+        if (blk < 0) {   // register tokens: rows >= nreg read the zero line
+#pragma unroll
+            for (int t = 0; t < PP; ++t) {
+                const int pid = wave * PP + t, j = pid & 3;
+                const bool isk = pid < 4;
+                const int rowin = 8 * j + lr8;
+                const bool ok = rowin < p.nreg;
+                const int swz = isk ? ((pc ^ ((rowin >> 1) & 7)) << 3) : ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
+                const uint16_t* g = ok ? (isk ? p.kreg : p.vreg) + (long)rowin * p.H * 64 + head * 64 + swz : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sK + pid * 1024), 16, 0, 0);
+            }
+        } else {
+            const int k0 = 32 * blk;
+            int base = k0;
+            if (p.perm_w) {
+                int f, patch, py, px;
+                if (perm_pow2) {
+                    f = k0 >> sh_hw;
+                    patch = (k0 & (p.perm_hw - 1)) >> 5;
+                    py = patch >> sh_ppr;
+                    px = patch & ((p.perm_w >> 3) - 1);
+                } else {
+                    f = k0 / p.perm_hw;
+                    patch = (k0 - f * p.perm_hw) >> 5;
+                    const int ppr = p.perm_w >> 3;
+                    py = patch / ppr;
+                    px = patch - py * ppr;
+                }
+                base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
+            }
+#pragma unroll
+            for (int t = 0; t < PP; ++t) {
+                const int pid = wave * PP + t;
+                if (pid < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lptr_t*)(sK + pid * 1024), 16, poff32[t], base * k_ls32 * 2, 0, 0);
+                else         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_t*)(sK + pid * 1024), 16, poff32[t], base * v_ls32 * 2, 0, 0);
+            }
+        }
+        const int wi = blk < 0 ? 0 : blk;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (lptr_t*)(mwring + stage * 256), 4, moff32, wi * 4, 0, 0);
+    };
+
+    float m_run = NEG_INF, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+
+    // every LDS address of the loop is a per-lane constant of stage 0 + an immediate offset (stage * 8192 ...): one set of address
+    // registers for all S stages
+    auto compute = [&](int blk, auto stc) __attribute__((always_inline)) {
+        constexpr int stage = decltype(stc)::value;
+        constexpr int KO = stage * 8192, VO = stage * 8192 + 4096;
+        const int left = blk < 0 ? p.nreg : min(32, p.Lk - 32 * blk);
+        const uint32_t lim = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        const uint32_t* wl = reinterpret_cast<const uint32_t*>(mwring + stage * 256);
+        const uint32_t mw = (blk < 0 ? 0xffffffffu : wl[r]) & lim;
+        if (!wave_active || __ballot(mw != 0u) == 0ull) return;
+        f32x16 sa;
+        {
+            uint32_t ad[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint32_t n0;
+                asm("v_bfe_u32 %0, %1, %2, 4" : "=v"(n0) : "v"(mw), "v"(8 * g4 + 4 * hh));
+                asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(ad[g4]) : "v"(n0), "v"(lut_addr));
+            }
+            f32x4 t0, t1, t2, t3;
+            bf16x8 kf0, kf1, kf2, kf3;
+            asm volatile(
+                "ds_read_b128 %4, %8 offset:%16\n\t"
+                "ds_read_b128 %0, %12\n\t"
+                "ds_read_b128 %1, %13\n\t"
+                "ds_read_b128 %2, %14\n\t"
+                "ds_read_b128 %3, %15\n\t"
+                "ds_read_b128 %5, %9 offset:%16\n\t"
+                "ds_read_b128 %6, %10 offset:%16\n\t"
+                "ds_read_b128 %7, %11 offset:%16\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(kf0), "=&v"(kf1), "=&v"(kf2), "=&v"(kf3)
+                : "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]), "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "n"(KO)
+                : "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa[j] = t0[j]; sa[4 + j] = t1[j]; sa[8 + j] = t2[j]; sa[12 + j] = t3[j]; }
+            const bf16x8 kfr[4] = {kf0, kf1, kf2, kf3};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sa, 0, 0, 0);
+        }
+        bf16x8 pf[2];
+        softmax_block32(sa, 0xffffffffu, true, hh, sl2, m_run, l_run, oacc, pf);
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments only now: 16 registers fewer across the softmax keep the wave within 128 (four waves per SIMD, whose MFMAs and
+        // vector work cover this read's latency)
+        bf16x8 vf[2][2];
+        {
+            bf16x4 u0, u1, u2, u3, u4, u5, u6, u7;
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+                "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+                "ds_read_b64_tr_b16 %2, %9 offset:%10\n\t"
+                "ds_read_b64_tr_b16 %3, %9 offset:%11\n\t"
+                "ds_read_b64_tr_b16 %4, %8 offset:%12\n\t"
+                "ds_read_b64_tr_b16 %5, %8 offset:%13\n\t"
+                "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+                "ds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6), "=&v"(u7)
+                : "v"(va0), "v"(va1), "n"(VO), "n"(VO + 1024), "n"(VO + 2048), "n"(VO + 3072)
+                : "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vf[0][0][j] = u0[j]; vf[0][0][4 + j] = u1[j];
+                vf[0][1][j] = u2[j]; vf[0][1][4 + j] = u3[j];
+                vf[1][0][j] = u4[j]; vf[1][0][4 + j] = u5[j];
+                vf[1][1][j] = u6[j]; vf[1][1][4 + j] = u7[j];
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf[s2], oacc[d], 0, 0, 0);
+    };
+
+    // retire the ordinary vector loads where hipcc can see it (see attn_sparse_kernel)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) asm volatile("" ::"v"(qf[s4]));
+    asm volatile("" ::"v"(my_word));
+
+    // ---- S-deep ring: blocks fifo[0] (current) .. fifo[S-2] are in flight or landed ----
+    int fifo[S - 1];
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j) {
+        fifo[j] = next_block();
+        if (fifo[j] != DONE) issue(fifo[j], j);
+    }
+    auto step = [&](auto stc) __attribute__((always_inline)) -> bool {
+        constexpr int st = decltype(stc)::value;
+        const int cur = fifo[0];
+        if (cur == DONE) return false;
+        // my own pieces of `cur` have landed when at most the operations of the blocks behind it are outstanding
+        if (fifo[S - 2] != DONE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * P) : "memory");
+        else {
+            bool waited = false;
+#pragma unroll
+            for (int a = S - 3; a >= 1; --a)
+                if (!waited && fifo[a] != DONE) {
+                    waited = true;
+                    if (a == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * P) : "memory");
+                    if (a == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+                    if (a == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * P) : "memory");
+                }
+            if (!waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const int nb = next_block();
+        if (nb != DONE) issue(nb, (st + S - 1) % S);
+        compute(cur, stc);
+#pragma unroll
+        for (int j = 0; j < S - 2; ++j) fifo[j] = fifo[j + 1];
+        fifo[S - 2] = nb;
+        return true;
+    };
+    for (;;) {
+        bool go = true;
+        if (go) go = step(std::integral_constant<int, 0>{});
+        if (go) go = step(std::integral_constant<int, 1>{});
+        if (go) go = step(std::integral_constant<int, 2>{});
+        if constexpr (S > 3) { if (go) go = step(std::integral_constant<int, 3>{}); }
+        if constexpr (S > 4) { if (go) go = step(std::integral_constant<int, 4>{}); }
+        if constexpr (S > 5) { if (go) go = step(std::integral_constant<int, 5>{}); }
+        if (!go) break;
+    }
+
+    {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        const int q = q0w + r;
+        if (q < p.Lq) {
+            uint16_t* op = p.o + bo * p.o_bso + bi * p.o_bsi + (long)ccv_patch_row(q, p.perm_hw, p.perm_w) * p.o_ls + head * 64;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = 32 * d + 8 * g4 + 4 * hh;
+                    uint2 pk = make_uint2(pack_bf16x2(oacc[d][4 * g4] * wgt, oacc[d][4 * g4 + 1] * wgt),
+                                          pack_bf16x2(oacc[d][4 * g4 + 2] * wgt, oacc[d][4 * g4 + 3] * wgt));
+                    *reinterpret_cast<uint2*>(op + dd) = pk;
+                }
+        }
+    }
+  }  // next item
+#endif
+}
+
+// =================================================================================================
 // attn_temporal_kernel: self attention over <= 16 tokens (the frames of one pixel), one wave per
 // (pixel, head).  HBM/L2-bound: Q and K fragments are loaded straight from the token-major activations
 // (16 rows x 64 B per instruction), S^T = K Q^T is two v_mfma_f32_16x16x32_bf16, the softmax runs on the
@@ -1138,28 +1466,29 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(!p.mask_bits || p.mask_words * 32 >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: mask_words too small");
     CCV_REQUIRE(!p.mask_bits || p.mask_nb > 0, CCV_EINVAL, "ccv_attn_fwd: mask_nb must be positive");
     CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
-    CCV_REQUIRE(p.variant != 3 || (p.wave_bits && !p.k2), CCV_EINVAL, "ccv_attn_fwd: variant 3 needs wave_bits and a single context");
+    CCV_REQUIRE(!(p.variant >= 3 && p.variant <= 6) || (p.wave_bits && !p.k2), CCV_EINVAL, "ccv_attn_fwd: variants 3-6 need wave_bits and a single context");
+    CCV_REQUIRE(p.variant >= 0 && p.variant <= 6, CCV_EINVAL, "ccv_attn_fwd: unknown variant %d", p.variant);
     CCV_REQUIRE(!p.wave_bits || (p.mask_bits && (long)p.wave_words * 32 * 32 >= p.Lk), CCV_EINVAL,
                 "ccv_attn_fwd: wave_bits needs mask_bits and wave_words covering Lk");
     CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
     CCV_REQUIRE(p.nreg <= KT, CCV_ESHAPE, "ccv_attn_fwd: at most 64 register tokens");
-    CCV_REQUIRE(p.perm_w == 0 || ((p.variant == 0 || p.variant == 3) && !p.k2 && p.perm_w % 8 == 0 && p.perm_hw > 0 && p.perm_hw % (4 * p.perm_w) == 0 &&
+    CCV_REQUIRE(p.perm_w == 0 || ((p.variant == 0 || p.variant >= 3) && !p.k2 && p.perm_w % 8 == 0 && p.perm_hw > 0 && p.perm_hw % (4 * p.perm_w) == 0 &&
                                   p.Lq % p.perm_hw == 0 && p.Lk % p.perm_hw == 0),
                 CCV_ESHAPE, "ccv_attn_fwd: patch order needs the single-context kernel, W %% 8 == 0, H %% 4 == 0 and whole frames");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gridDim.z is limited to 65535: fold large batches (temporal attention: one batch per pixel)
-    const bool temporal_path = (p.variant == 0 || p.variant == 3) && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16 && p.perm_w == 0;
+    const bool temporal_path = (p.variant == 0 || p.variant >= 3) && !p.k2 && !p.mask_bits && !p.kreg && p.Lq == p.Lk && p.Lk <= 16 && p.perm_w == 0;
     CCV_REQUIRE(temporal_path || p.B <= 65535, CCV_ESHAPE, "ccv_attn_fwd: B=%d exceeds 65535 (split the call)", p.B);
     dim3 grid((p.Lq + 127) / 128, p.H, p.B);
     if (temporal_path) {
         // frames-of-a-pixel attention: one wave per (batch, head), no key tiling
         const long items = (long)p.B * p.H;
         hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
-    } else if ((p.variant == 0 || p.variant == 3) && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
+    } else if ((p.variant == 0 || p.variant >= 3) && p.k2 == nullptr) {  // single-context attention: second-generation kernel, 256 queries per workgroup
         const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
         CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
         dim3 grid2((unsigned)nwg2);
-        if (p.mask_bits && p.wave_bits && (p.variant == 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024)) {
+        if (p.mask_bits && p.wave_bits && (p.variant >= 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024)) {
             // persistent: 2 workgroups per CU (LDS-bound), fewer when there are fewer 64-query groups than waves
             static std::atomic<int> next_slot{0};
             CCV_REQUIRE(p.k_ls >= 0 && p.v_ls >= 0 && (long)p.Lk * p.k_ls < (1l << 31) && (long)p.Lk * p.v_ls < (1l << 31), CCV_ESHAPE,
@@ -1197,6 +1526,24 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             a.order_bs = (int32_t)order_bs;
             a.B = p.B; a.inner = p.inner; a.H = p.H; a.Lq = p.Lq; a.Lk = p.Lk; a.nreg = p.kreg ? p.nreg : 0; a.perm_hw = p.perm_hw; a.perm_w = p.perm_w;
             a.scale = p.scale; a.slot = slot; a.use_xcd_queues = xcd_queues;
+            a.wg_order = nullptr; a.wg_order_bs = 0;
+            // round 4: K / V blocks shared by the workgroup (attn_shared_kernel).  variant 4 / 5 force the 8- / 4-wave form, variant 6 the
+            // per-wave kernel; otherwise CCV_ATTN_SHARED = 8 (default) | 4 | 0 (A/B aid)
+            static const int shared_env = [] { const char* e = getenv("CCV_ATTN_SHARED"); const int v = e ? atoi(e) : 8; return (v == 8 || v == 4) ? v : 0; }();
+            const int nw = p.variant == 4 ? 8 : (p.variant == 5 ? 4 : (p.variant == 6 ? 0 : shared_env));
+            if (nw) {
+                const int merge = nw / 2;                         // 64-query groups per item
+                const long g64 = (p.Lq + 63) / 64, items_per = (g64 + merge - 1) / merge;
+                if (p.wg_order && p.wg_merge == merge) {
+                    CCV_REQUIRE(p.wg_order_bs >= items_per && p.wg_order_bs < (1l << 31), CCV_EINVAL, "ccv_attn_fwd: wg_order_bs too small");
+                    a.wg_order = p.wg_order; a.wg_order_bs = (int32_t)p.wg_order_bs;
+                }
+                const long items = items_per * p.H * p.B;
+                const long cap_s = pct * n_cu / 100 * (nw == 8 ? 1 : 2);   // 2 x 512 or 4 x 256 threads per CU
+                const long wgs_s = items < cap_s ? items : cap_s;
+                if (nw == 8) hipLaunchKernelGGL((attn_shared_kernel<8, 4>), dim3((unsigned)wgs_s), dim3(512), 0, st, a);
+                else         hipLaunchKernelGGL((attn_shared_kernel<4, 4>), dim3((unsigned)wgs_s), dim3(256), 0, st, a);
+            } else
             hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
         }
         else if (p.mask_bits)

@@ -321,20 +321,28 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, uint1
 // Longest-first schedule of the sparse attention kernel: one workgroup per mask batch counts the needed key
 // blocks of every 64-query group (popcount of its wave_bits row) and rank-sorts the groups (O(n^2), n <= 8192,
 // once per clip).
-__global__ __launch_bounds__(256) void group_order_kernel(const uint32_t* wave_bits, int ngroups, int words, int32_t* order) {
+// merge > 1: an item is `merge` consecutive groups and counts the blocks ANY of them needs (the OR of their rows): the items of the
+// workgroup-shared sparse kernel.
+__global__ __launch_bounds__(256) void group_order_kernel(const uint32_t* wave_bits, int ngroups, int words, int merge, int32_t* order) {
     __shared__ int cnt[8192];
     const uint32_t* wb = wave_bits + (long)blockIdx.x * ngroups * words;
-    for (int i = threadIdx.x; i < ngroups; i += 256) {
+    const int nitems = (ngroups + merge - 1) / merge;
+    for (int i = threadIdx.x; i < nitems; i += 256) {
         int c = 0;
-        for (int w = 0; w < words; ++w) c += __popc(wb[(long)i * words + w]);
+        for (int w = 0; w < words; ++w) {
+            uint32_t u = 0u;
+            for (int j = 0; j < merge; ++j)
+                if (i * merge + j < ngroups) u |= wb[(long)(i * merge + j) * words + w];
+            c += __popc(u);
+        }
         cnt[i] = c;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ngroups; i += 256) {
+    for (int i = threadIdx.x; i < nitems; i += 256) {
         const int ci = cnt[i];
         int rank = 0;
-        for (int j = 0; j < ngroups; ++j) rank += (cnt[j] > ci || (cnt[j] == ci && j < i)) ? 1 : 0;
-        order[(long)blockIdx.x * ngroups + rank] = i;
+        for (int j = 0; j < nitems; ++j) rank += (cnt[j] > ci || (cnt[j] == ci && j < i)) ? 1 : 0;
+        order[(long)blockIdx.x * nitems + rank] = i;
     }
 }
 
@@ -480,8 +488,18 @@ extern "C" int ccv_epipolar_mask_bits_rect(const float* F, uint32_t* bits, uint8
 extern "C" int ccv_attn_group_order(const uint32_t* wave_bits, int32_t B, int32_t ngroups, int32_t wave_words, int32_t* order, void* stream) {
     CCV_REQUIRE(wave_bits && order && B > 0 && ngroups > 0 && wave_words > 0, CCV_EINVAL, "ccv_attn_group_order: bad args");
     CCV_REQUIRE(ngroups <= 8192, CCV_ESHAPE, "ccv_attn_group_order: at most 8192 query groups (Lq <= 524288)");
-    hipLaunchKernelGGL(group_order_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), wave_bits, ngroups, wave_words, order);
+    hipLaunchKernelGGL(group_order_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), wave_bits, ngroups, wave_words, 1, order);
     CCV_LAUNCH_CHECK("ccv_attn_group_order");
+    return CCV_OK;
+}
+
+extern "C" int ccv_attn_group_order_merged(const uint32_t* wave_bits, int32_t B, int32_t ngroups, int32_t wave_words, int32_t merge, int32_t* order,
+                                           void* stream) {
+    CCV_REQUIRE(wave_bits && order && B > 0 && ngroups > 0 && wave_words > 0, CCV_EINVAL, "ccv_attn_group_order_merged: bad args");
+    CCV_REQUIRE(merge >= 1 && merge <= 8, CCV_EINVAL, "ccv_attn_group_order_merged: merge must be 1 .. 8 (got %d)", merge);
+    CCV_REQUIRE((ngroups + merge - 1) / merge <= 8192, CCV_ESHAPE, "ccv_attn_group_order_merged: at most 8192 items");
+    hipLaunchKernelGGL(group_order_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), wave_bits, ngroups, wave_words, merge, order);
+    CCV_LAUNCH_CHECK("ccv_attn_group_order_merged");
     return CCV_OK;
 }
 

@@ -365,10 +365,16 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
             p.wave_words = wave_bits.shape[-1]
             p.wave_bs = wave_bits.shape[-2] * wave_bits.shape[-1]
             if group_order is not None:
-                if group_order.dtype != torch.int32 or not group_order.is_contiguous() or group_order.shape[-1] != wave_bits.shape[-2]:
-                    raise CcvError("attention: group_order must be contiguous int32 [mask_nb, ceil(Lq/64)]")
+                g64 = wave_bits.shape[-2]
+                n_wg = (g64 + WG_MERGE - 1) // WG_MERGE
+                if group_order.dtype != torch.int32 or not group_order.is_contiguous() or group_order.shape[-1] not in (g64, g64 + n_wg):
+                    raise CcvError("attention: group_order must be contiguous int32 [mask_nb, ceil(Lq/64)] (+ the merged order, attn_group_order)")
                 p.group_order = _ptr(group_order)
                 p.order_bs = group_order.shape[-1]
+                if group_order.shape[-1] == g64 + n_wg:   # the workgroup-shared kernel's items ride behind the 64-query groups' order
+                    p.wg_order = C.c_void_p(group_order.data_ptr() + 4 * g64)
+                    p.wg_order_bs = group_order.shape[-1]
+                    p.wg_merge = WG_MERGE
     if kreg is not None:
         p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
     if perm is not None:   # (frame tokens, frame width): rows and mask are in 4x8-patch order
@@ -770,13 +776,23 @@ class MaskPack(tuple):
         return self
 
 
-def attn_group_order(wave_bits):
-    """wave_bits int32 [B, groups, words] -> int32 [B, groups]: groups by decreasing popcount (sparse-kernel schedule)."""
+WG_MERGE = 4   # 64-query groups per item of the workgroup-shared sparse kernel's default form (8 waves x 32 queries)
+
+
+def attn_group_order(wave_bits, merged=True):
+    """wave_bits int32 [B, groups, words] -> int32 [B, groups (+ ceil(groups / WG_MERGE))]: the 64-query groups by decreasing popcount
+    (per-wave sparse kernel's schedule) and, behind them in the same rows, the items of WG_MERGE consecutive groups by decreasing size
+    of the union of their key blocks (workgroup-shared kernel's schedule; ops.attention splits the two)."""
     _dev(wave_bits)
     B, groups, words = wave_bits.shape
     order = torch.empty((B, groups), dtype=torch.int32, device=wave_bits.device)
     check(lib().ccv_attn_group_order(_ptr(wave_bits), B, groups, words, _ptr(order), _stream()), "ccv_attn_group_order")
-    return order
+    if not merged:
+        return order
+    n_wg = (groups + WG_MERGE - 1) // WG_MERGE
+    worder = torch.empty((B, n_wg), dtype=torch.int32, device=wave_bits.device)
+    check(lib().ccv_attn_group_order_merged(_ptr(wave_bits), B, groups, words, WG_MERGE, _ptr(worder), _stream()), "ccv_attn_group_order_merged")
+    return torch.cat([order, worder], dim=1).contiguous()
 
 
 def patch_order_ok(H, W):

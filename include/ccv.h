@@ -224,13 +224,20 @@ typedef struct CcvAttn {
                               * the mask must have been built with the same values */
     int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; unmasked two-context calls run both softmaxes in it);
                          1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging;
-                         3: as 0 but always the per-wave sparse kernel when wave_bits is given (0 picks it from 1024
-                            64-query groups upwards and the tiled masked kernel below that) */
+                         3: as 0 but always a persistent sparse kernel when wave_bits is given (0 picks it from 1024
+                            64-query groups upwards and the tiled masked kernel below that);
+                         4 / 5: as 3, the workgroup-shared sparse kernel with 8 / 4 waves (256 / 128 queries) per workgroup;
+                         6: as 3, the per-wave sparse kernel (every wave streams its own K / V blocks) */
     uint32_t* queue_counters; /* NULL or 8 uint32 that the caller ZEROED on `stream` before the call: the work-queue counters of
                               * the persistent sparse kernel (wave_bits path).  With caller-owned counters the call keeps no
                               * state in the library, so launches may overlap freely on different streams (two clips in
                               * flight, two graphs replayed concurrently).  NULL: a row of the library's rotating pool of 64
                               * counter rows, reset by a one-block launch in front of the kernel. */
+    const int32_t* wg_order; int64_t wg_order_bs; int32_t wg_merge; /* NULL or [mask_nb, ceil(ceil(Lq/64) / wg_merge)] int32 from
+                              * ccv_attn_group_order_merged: the items of the workgroup-shared sparse kernel (wg_merge consecutive
+                              * 64-query groups whose K / V blocks one workgroup stages once: 4 for its 8-wave form, 2 for the
+                              * 4-wave form) by decreasing size of the union of their needed key blocks.  NULL or another
+                              * wg_merge than the kernel's: items are handed out in index order (same result, longer tail). */
 } CcvAttn;
 int ccv_attn_fwd(const CcvAttn* p, void* stream);
 /* Self-attention over Lq = Lk <= 16 tokens with an arbitrary head width (multiple of 8, <= 256): the temporal blocks of
@@ -395,6 +402,10 @@ int64_t ccv_attn_sparse_queue_item(int32_t nbh, int32_t ngroups, int32_t xq, int
  * order[b][r] = index of the 64-query group with the r-th largest popcount of its wave_bits row (ties: lower index first).
  * wave_bits [B, ngroups, wave_words], order [B, ngroups] int32; ngroups <= 8192. */
 int ccv_attn_group_order(const uint32_t* wave_bits, int32_t B, int32_t ngroups, int32_t wave_words, int32_t* order, void* stream);
+/* The same for items of `merge` consecutive 64-query groups (CcvAttn.wg_order): order [B, ceil(ngroups / merge)] = the items by
+ * decreasing popcount of the OR of their wave_bits rows.  merge in 1 .. 8. */
+int ccv_attn_group_order_merged(const uint32_t* wave_bits, int32_t B, int32_t ngroups, int32_t wave_words, int32_t merge, int32_t* order,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -454,11 +454,63 @@ def test_attention_masked_register_tokens(ops, variant, L, density):
     # longest-first schedule: groups by decreasing number of needed key blocks, ties by index; same result with it
     cnt = ref_need.sum(1).numpy()
     want = np.array(sorted(range(nq), key=lambda i: (-cnt[i], i)), dtype=np.int32)
-    assert np.array_equal(mp.group_order.cpu().numpy()[0], want)
+    assert np.array_equal(mp.group_order.cpu().numpy()[0, :nq], want)
+    # behind it: the workgroup-shared kernel's items (ops.WG_MERGE consecutive groups, union of their blocks), longest first
+    mg = ops.WG_MERGE
+    ni = (nq + mg - 1) // mg
+    pad = np.zeros((ni * mg, ref_need.shape[1]), dtype=bool)
+    pad[:nq] = ref_need.numpy()
+    ucnt = pad.reshape(ni, mg, -1).any(1).sum(1)
+    want_wg = np.array(sorted(range(ni), key=lambda i: (-ucnt[i], i)), dtype=np.int32)
+    assert np.array_equal(mp.group_order.cpu().numpy()[0, nq:], want_wg)
     out4 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=(L * ld, 0, ld),
                          k_str=(L * ld, 0, ld), v_str=(L * ld, 0, ld), mask_bits=bits, mask_nb=1, tile_flags=flags,
                          wave_bits=mp.wave_bits, group_order=mp.group_order, kreg=kreg, vreg=vreg, variant=3 if variant == 0 else variant)
     assert torch.equal(out3, out4)   # each group is still computed by one wave in the same block order
+
+
+@pytest.mark.parametrize("L,H,density,perm", [(1024, 2, 0.04, None), (320, 2, 0.3, None), (48, 2, 0.5, None), (6 * 128, 3, 0.06, (128, 16)),
+                                              (5 * 288, 2, 0.05, (288, 24)), (16 * 256, 5, 0.02, (256, 16))])
+def test_attention_shared_kv_kernel(ops, L, H, density, perm):
+    """Round 4: the workgroup-shared sparse kernel (variant 4: 8 waves x 32 queries, variant 5: 4 waves; K / V blocks of the union of
+    the workgroup's bitmaps staged once into a 4-deep ring) against torch fp32 and, BIT FOR BIT, against the per-wave sparse kernel
+    (variant 6): every query meets the same key blocks in the same order in all three; ragged last groups, rows that only see
+    the register tokens, empty bands, both patch-grid arithmetic paths, with and without the longest-first item order."""
+    B, nreg = 2, 4
+    C = H * 64
+    g = torch.Generator().manual_seed(130 + L)
+    mask = torch.rand(1, L, L, generator=g) < density
+    mask[:, :, : L // 3] &= (torch.rand(1, L, 1, generator=g) < 0.5)
+    if L >= 256:
+        mask[:, :128, 64:192] = False
+        mask[:, 5] = False
+        mask[:, 200:240] = False              # a whole wave's queries (and more) see nothing but the registers
+    mask = mask.to(dev())
+    mp = ops.pack_mask(mask, perm)
+    bits, flags = mp
+    qkv = rnd(B * L, 3 * C, seed=131)
+    kreg, vreg = rnd(nreg, C, seed=132), rnd(nreg, C, seed=133)
+    ld = 3 * C
+    st = (L * ld, 0, ld)
+    kw = dict(B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st, mask_bits=bits, mask_nb=1, tile_flags=flags, wave_bits=mp.wave_bits,
+              kreg=kreg, vreg=vreg, perm=perm)
+    per_wave = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=6, group_order=mp.group_order, **kw)
+    x = qkv.float().reshape(B, L, 3, H, 64)
+    k = torch.cat([kreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)
+    v = torch.cat([vreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 2]], 1)
+    m = F.pad(mask.expand(B, -1, -1), (nreg, 0), value=True)
+    ref = ref_attn(x[:, :, 0], k, v, m)
+    assert_close(per_wave.reshape(B, L, H, 64), ref, 1.5e-2, f"per-wave kernel L={L}")
+    for variant in (4, 5):
+        for order in (mp.group_order, None):
+            out = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=variant, group_order=order, **kw)
+            assert_close(out.reshape(B, L, H, 64), ref, 1.5e-2, f"shared kernel v{variant} L={L}")
+            assert torch.equal(out, per_wave), f"variant {variant} (order given: {order is not None}) differs from the per-wave kernel"
+    # no register tokens
+    kw2 = dict(kw, kreg=None, vreg=None)
+    a = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=6, group_order=mp.group_order, **kw2)
+    b4 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=4, group_order=mp.group_order, **kw2)
+    assert torch.equal(a, b4)
 
 
 @pytest.mark.parametrize("fh,fw", [(8, 16), (12, 24)])

@@ -55,10 +55,15 @@ def timeit(fn, n):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+variants = [int(v) for v in os.environ.get("SPARSE_PROBE_VARIANTS", "6,4,5").split(",")]   # 6 per-wave, 4 / 5 workgroup-shared (8 / 4 waves)
 for qkv, H, kw, L in calls:
-    fn = lambda: [ops.attention(qkv, qkv[:, H * 64:], qkv[:, 2 * H * 64:], **kw) for _ in range(5)]
-    us = timeit(fn, reps) / 5
-    alg = (2 * L * 3 * H * 64 * 2) / 3 * 4 / 3   # q, k, v read + o written, bf16
-    alg = 2 * L * H * 64 * 2 * 4 + kw["mask_bits"].numel() * 4
-    print(f"sparse L={L} H={H} b=2: {us:8.1f} us/launch   dense-equivalent {4.0 * L * L * 64 * H * 2 / us / 1e6:7.1f} TF/s   "
-          f"algorithmic bytes {alg / 1e6:.1f} MB (q,k,v,o + mask bits)   CCV_ATTN_XCD={os.environ.get('CCV_ATTN_XCD', '0')}")
+    ref = None
+    for variant in variants:
+        fn = lambda: [ops.attention(qkv, qkv[:, H * 64:], qkv[:, 2 * H * 64:], variant=variant, **kw) for _ in range(5)]
+        us = timeit(fn, reps) / 5
+        out = kw["out"].clone()
+        same = "" if ref is None else f"   bit-identical to variant {variants[0]}: {torch.equal(out, ref)}"
+        ref = out if ref is None else ref
+        alg = 2 * L * H * 64 * 2 * 4 + kw["mask_bits"].numel() * 4
+        print(f"sparse L={L} H={H} b=2 variant {variant}: {us:8.1f} us/launch   dense-equivalent {4.0 * L * L * 64 * H * 2 / us / 1e6:7.1f} TF/s   "
+              f"algorithmic bytes {alg / 1e6:.1f} MB (q,k,v,o + mask bits){same}", flush=True)
