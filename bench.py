@@ -39,12 +39,66 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # PMC-derived bytes of this round's profile run
 
 
-def build_model(device, unet_params=None):
+# BASELINE.json configs -> concrete runs (SURVEY.md section 8d "Configs -> concrete runs").  c1 is the metric's configuration and the
+# default; the others are supplementary lines (`python bench.py --config c3`), committed under profiles/.
+WORKLOADS = {
+    "c1": dict(target="model.camcontexti2v.CamContextI2V", T=16, cfg=7.5, camera=True, cond_ctx=77 + 256 * (1 + N_CONTEXT), uncond_ctx=77 + 256,
+               metric="denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
+               label="CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, 25 DDIM steps, CFG 7.5, "
+                     "guidance_rescale 0.7, eta 1.0"),
+    "c0": dict(target="model.dynamicrafter.DynamiCrafter", T=16, cfg=1.0, camera=False, cond_ctx=77 + 256, uncond_ctx=None,
+               metric="denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG off (DynamiCrafter 256 base, BASELINE.json configs[0])",
+               label="DynamiCrafter-256 base (no camera), 1 clip x 16 frames x 256x256, 25 DDIM steps, CFG off (25 UNet forwards, b = 1), "
+                     "context 77 + 16 x 16 tokens per frame, eta 1.0"),
+    "c3": dict(target="baseline.cami2v.CamI2V", T=16, cfg=7.5, camera=True, cond_ctx=77 + 256, uncond_ctx=77 + 256,
+               metric="denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5 (CamI2V 256 baseline, BASELINE.json configs[3])",
+               label="CamI2V-256 baseline (configs/baseline/cami2v_256.yaml: Pluecker features + epipolar attention, context 77 + 16 x 16 "
+                     "per frame on both CFG passes, no context-frame adaptor), 1 clip x 16 frames x 256x256, 25 DDIM steps, CFG 7.5, "
+                     "guidance_rescale 0.7, eta 1.0"),
+    "c4": dict(target="model.camcontexti2v.CamContextI2V", T=32, cfg=3.5, camera=True, cond_ctx=77 + 16 * 32, uncond_ctx=77 + 16 * 32,
+               metric="denoised video frames/sec at 32x256x256, 25 DDIM steps, CFG=3.5 (BASELINE.json configs[4], UNet level)",
+               label="CamContextI2V-256 UNet at 32 frames (SURVEY.md section 8d C5: the reference cannot run t = 32 end to end; synthetic pose "
+                     "features and epipolar masks of a 32-frame trajectory, context 77 + 16 x 32 on both CFG passes), 1 clip x 32 frames x "
+                     "256x256, 25 DDIM steps, CFG 3.5, guidance_rescale 0.7, eta 1.0; bf16 epipolar attention (the e4m3 variant was "
+                     "measured slower and retired, profiles/r04_fp8_retired.txt)"),
+}
+
+
+def workload_tflop_per_clip(w):
+    """Algorithmic TFLOP of one clip by SURVEY.md section 8(d)'s dense convention."""
+    from camc2v_amd import configs
+    if w["T"] == 32:
+        # per forward at t = 32: everything per-frame doubles (2 x (4.904 no-camera + 0.256 camera linears)), the epipolar attention over
+        # T*h*w tokens quadruples (4 x 1.963); both CFG passes carry the camera and the per-frame context
+        per_fwd = 2 * (configs.TFLOP_NOCAM + 0.256) + 4 * 1.963
+        return 25 * 2 * per_fwd
+    if not w["camera"]:
+        return 25 * configs.TFLOP_NOCAM
+    if w["cond_ctx"] == 77 + 256:
+        return 25 * 2 * configs.TFLOP_UNCOND_CAM
+    return 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
+
+
+WORKLOAD = WORKLOADS["c1"]       # set by main() from --config
+WORKLOAD_KEY = "c1"
+
+
+def build_model(device, unet_params=None, workload=None):
     from camc2v_amd import configs
     from utils.utils import instantiate_from_config
+    w = workload or WORKLOAD
     torch.manual_seed(SEED)
+    cfg = configs.camcontexti2v_256(unet_params if unet_params is not None else dict(configs.UNET_256, temporal_length=w["T"]))
+    cfg["target"] = w["target"]
+    cfg["params"]["temporal_length"] = w["T"]
+    if w["target"] != "model.camcontexti2v.CamContextI2V":      # the baselines take no context-frame arguments
+        for k in ("multi_cond_strategy", "use_zero_conv_latent_input"):
+            cfg["params"].pop(k, None)
+    if not w["camera"]:
+        for k in ("add_type", "pose_encoder_config", "epipolar_config"):
+            cfg["params"].pop(k, None)
     with torch.device(device):
-        model = instantiate_from_config(configs.camcontexti2v_256(unet_params))
+        model = instantiate_from_config(cfg)
     g = torch.Generator(device=device).manual_seed(SEED)
     with torch.no_grad():  # seeded N(0, 0.02) weights incl. the zero-initialised tensors; norm gains ~ 1
         for name, p in model.model.diffusion_model.named_parameters():
@@ -56,26 +110,37 @@ def build_model(device, unet_params=None):
     return model
 
 
-def synthetic_inputs(model, device, b=1, t=16, hl=32, rank=0, clip=0):
+def synthetic_inputs(model, device, b=1, t=None, hl=32, rank=0, clip=0, workload=None):
     """SURVEY.md section 8(d) synthetic clip; (rank, clip) select the random draws, the camera trajectory is the fixed one."""
     from camc2v_amd import camera
+    w = workload or WORKLOAD
+    t = w["T"] if t is None else t
     g = torch.Generator(device=device).manual_seed(SEED + 17 * rank + 1009 * clip)
     rn = lambda *s: torch.randn(*s, device=device, generator=g)
     ctx_dim = 1024
-    img = torch.nn.functional.layer_norm(rn(b, 256 * (1 + N_CONTEXT), ctx_dim), (ctx_dim,))
-    img_u = torch.nn.functional.layer_norm(rn(b, 16 * t, ctx_dim), (ctx_dim,))
-    cond_ctx = torch.cat([rn(b, 77, ctx_dim), img], 1).contiguous()
-    uncond_ctx = torch.cat([rn(b, 77, ctx_dim), img_u], 1).contiguous()
+
+    def context(L):
+        img = torch.nn.functional.layer_norm(rn(b, L - 77, ctx_dim), (ctx_dim,))
+        return torch.cat([rn(b, 77, ctx_dim), img], 1).contiguous()
+    if w is WORKLOADS["c1"]:      # (draw order of rounds 1-3 kept: the committed parity numbers refer to these tensors)
+        img = torch.nn.functional.layer_norm(rn(b, 256 * (1 + N_CONTEXT), ctx_dim), (ctx_dim,))
+        img_u = torch.nn.functional.layer_norm(rn(b, 16 * t, ctx_dim), (ctx_dim,))
+        cond_ctx = torch.cat([rn(b, 77, ctx_dim), img], 1).contiguous()
+        uncond_ctx = torch.cat([rn(b, 77, ctx_dim), img_u], 1).contiguous()
+    else:
+        cond_ctx = context(w["cond_ctx"])
+        uncond_ctx = context(w["uncond_ctx"]) if w["uncond_ctx"] else None
     c_concat = (rn(b, 4, t, hl, hl) * 0.18215).contiguous()
-    chans = [320, 640, 1280, 1280]
-    feats = [(rn(b, chans[i], t, hl >> i, hl >> i) * 0.1).contiguous() for i in range(4)]
-    px = 8 * hl
-    K = torch.tensor([[px / 2, 0, px / 2], [0, px / 2, px / 2], [0, 0, 1.0]], device=device).repeat(b, t, 1, 1)
-    w2c = camera.synthetic_trajectory(b, t, device)
-    cam = model.camera_condition(K, w2c, torch.zeros(b, dtype=torch.long, device=device), px, px,
-                                 pluker_features=feats, generator=g)
-    cond = dict(c_concat=[c_concat], c_crossattn=[cond_ctx], camera_condition=cam)
-    uncond = dict(c_concat=[c_concat], c_crossattn=[uncond_ctx])
+    cond = dict(c_concat=[c_concat], c_crossattn=[cond_ctx])
+    if w["camera"]:
+        chans = [320, 640, 1280, 1280]
+        feats = [(rn(b, chans[i], t, hl >> i, hl >> i) * 0.1).contiguous() for i in range(4)]
+        px = 8 * hl
+        K = torch.tensor([[px / 2, 0, px / 2], [0, px / 2, px / 2], [0, 0, 1.0]], device=device).repeat(b, t, 1, 1)
+        w2c = camera.synthetic_trajectory(b, t, device)
+        cond["camera_condition"] = model.camera_condition(K, w2c, torch.zeros(b, dtype=torch.long, device=device), px, px,
+                                                          pluker_features=feats, generator=g)
+    uncond = dict(c_concat=[c_concat], c_crossattn=[uncond_ctx]) if uncond_ctx is not None else None
     fs = torch.full((b,), 8, dtype=torch.long, device=device)
     x_T = rn(b, 4, t, hl, hl)
     noises = [rn(b, 4, t, hl, hl) for _ in range(25)]
@@ -86,9 +151,21 @@ def sample_clip(model, cond, uncond, fs, x_T, noises, use_graph):
     from camc2v_amd import configs
     kw = dict(configs.GENERATION_KWARGS)
     steps = kw.pop("ddim_steps")
+    kw["unconditional_guidance_scale"] = WORKLOAD["cfg"]
+    kw["enable_camera_condition"] = WORKLOAD["camera"]
     samples, _ = model.sample_log(cond, x_T.shape[0], True, steps, x_T=x_T, unconditional_conditioning=uncond,
                                   fs=fs, injected_noise=noises, use_graph=use_graph, **kw)
     return samples
+
+
+def cfg_step(model, device, inputs, t_value=439):
+    """One sampler step's UNet work on the clip `inputs`: the cond + uncond pair the sampler runs under CFG, one forward without."""
+    cond, uncond, fs, x_T, _ = inputs
+    t = torch.full((x_T.shape[0],), t_value, dtype=torch.long, device=device)
+    if uncond is None:
+        return (model.apply_model(x_T, t, cond, fs=fs),)
+    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True)) if WORKLOAD["camera"] else uncond
+    return model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=WORKLOAD["camera"])
 
 
 def host_cores():
@@ -98,43 +175,49 @@ def host_cores():
 
 
 def cpu_baseline(model, device, inputs):
-    """The oracle (fp32 CPU restatement of the reference's UNet) timed on the host cores on the metric's own workload:
-    ONE classifier-free-guidance step of the benchmark clip = the camera-conditioned conditional forward (context 77 +
-    768 tokens) + the camera-conditioned unconditional forward (77 + 256), same weights, inputs and epipolar masks as
-    the GPU run (bounded sample: 2 of the clip's 50 forwards).  The same two outputs give the full-size parity of the
-    HIP path (`apply_model_pair`, what the sampler runs)."""
+    """The oracle (fp32 CPU restatement of the reference's UNet) timed on the host cores on the workload's own step: ONE sampler
+    step of the benchmark clip -- under CFG the conditional + the unconditional forward (c1: camera-conditioned, context 77 + 768 and
+    77 + 256 tokens; c3: 77 + 256 both), without CFG (c0) the one forward -- same weights, inputs and epipolar masks as the GPU run
+    (bounded sample: 1 of the clip's 25 steps).  The same outputs give the full-size parity of the HIP path (what the sampler runs)."""
     from oracle import geometry_oracle, unet_oracle
     from camc2v_amd import configs
+    w = WORKLOAD
+    if w["T"] != 16:
+        return dict(value=None, unit="frames/s", cores=host_cores(), kind="port",
+                    sample="not run: the oracle's dense fp32 epipolar attention over 32768 x 32768 scores (4.3 GB per head) does not fit a "
+                           "bounded CPU sample; configs[4] is held to the oracle at reduced width in tests/test_unet_gpu.py"), None
     cond, uncond, fs, x_T, _ = inputs
     unet = model.model.diffusion_model
     t = torch.full((1,), 439, dtype=torch.long, device=device)
-    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True))
     with torch.no_grad():
-        e_c, e_uc = model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)
-    e_c, e_uc = e_c.float().cpu(), e_uc.float().cpu()
+        got = [e.float().cpu() for e in cfg_step(model, device, inputs)]
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-    cam = cond["camera_condition"]
-    F = cam["fundamental"].float().cpu()
-    masks = {d: geometry_oracle.epipolar_mask(F, 256 // d, 256 // d, d) for d in (8, 16, 32, 64)}
-    cam_cpu = dict(pluker_embedding_features=[f.float().cpu() for f in cam["pluker_embedding_features"]],
-                   sample_locs_dict=masks, add_type=cam["add_type"])
+    cam_cpu = None
+    if w["camera"]:
+        cam = cond["camera_condition"]
+        F = cam["fundamental"].float().cpu()
+        masks = {d: geometry_oracle.epipolar_mask(F, 256 // d, 256 // d, d) for d in (8, 16, 32, 64)}
+        cam_cpu = dict(pluker_embedding_features=[f.float().cpu() for f in cam["pluker_embedding_features"]],
+                       sample_locs_dict=masks, add_type=cam["add_type"])
     x = torch.cat([x_T, cond["c_concat"][0]], 1).float().cpu()
     cores = host_cores()
     torch.set_num_threads(cores)
     secs, parity = [], {}
-    for got, ctx, what in ((e_c, cond["c_crossattn"][0], "cond"), (e_uc, uncond["c_crossattn"][0], "uncond")):
+    passes = [(got[0], cond["c_crossattn"][0], "cond")] + ([(got[1], uncond["c_crossattn"][0], "uncond")] if uncond is not None else [])
+    for g_, ctx, what in passes:
         t0 = time.perf_counter()
         with torch.no_grad():
-            ref = unet_oracle.unet_forward(sd, configs.UNET_256, x, t.cpu(), ctx.float().cpu(), fs.cpu(), cam_cpu, origin_h=256)
+            ref = unet_oracle.unet_forward(sd, dict(configs.UNET_256), x, t.cpu(), ctx.float().cpu(), fs.cpu(), cam_cpu, origin_h=256)
         secs.append(time.perf_counter() - t0)
-        parity[f"{what}_rel_l2"] = ((got - ref).norm() / ref.norm()).item()
-        parity[f"{what}_max_rel"] = ((got - ref).abs().max() / ref.abs().max()).item()
-    parity["case"] = ("full-size camera-conditioned CFG step (cond ctx 845 + uncond ctx 333, b=1, 32x32 latents, native packed "
-                      "masks) vs the fp32 oracle")
+        parity[f"{what}_rel_l2"] = ((g_ - ref).norm() / ref.norm()).item()
+        parity[f"{what}_max_rel"] = ((g_ - ref).abs().max() / ref.abs().max()).item()
+    ctxs = " + ".join(f"{what} ctx {c.shape[1]}" for _, c, what in passes)
+    parity["case"] = f"full-size sampler step ({ctxs}, b=1, 32x32 latents{', native packed masks' if w['camera'] else ''}) vs the fp32 oracle"
     value = 16.0 / (25.0 * sum(secs))
     return dict(value=value, unit="frames/s", cores=cores, kind="port",
-                sample=f"1 of the clip's 25 CFG steps = 2 camera-conditioned UNet forwards (fp32 oracle, b=1): cond ctx 845 = "
-                       f"{secs[0]:.2f} s, uncond ctx 333 = {secs[1]:.2f} s; value = 16 frames / (25 x their sum)",
+                sample=f"1 of the clip's 25 sampler steps = {len(passes)} UNet forward(s) (fp32 oracle, b=1): "
+                       + ", ".join(f"{what} ctx {c.shape[1]} = {sec:.2f} s" for (_, c, what), sec in zip(passes, secs))
+                       + "; value = 16 frames / (25 x their sum)",
                 seconds_per_cfg_step=sum(secs)), parity
 
 
@@ -236,21 +319,37 @@ def gather_latents(dist, world):
 
 
 # ---- the dominant kernel, timed live ---------------------------------------------------------------------------------
+def _block_fractions(bits, wbits, L):
+    """(fraction of (64-query group, 32-key block) pairs with a visible key = what the per-wave kernel visits, both halves each;
+    fraction of (32-query patch, 32-key block) pairs with a visible key = the half-blocks the workgroup-shared kernel multiplies)."""
+    nblk = (L + 31) // 32
+    words = wbits.reshape(-1).to(torch.int64) & 0xFFFFFFFF
+    pop = sum(int(((words >> i) & 1).sum()) for i in range(32))
+    visited64 = pop / (wbits.shape[0] * wbits.shape[1] * nblk)
+    nb = bits.shape[0]
+    half = (bits.reshape(nb, L // 32, 32, bits.shape[-1]) != 0).any(dim=2)[..., :nblk]
+    return visited64, float(half.float().mean())
+
+
 def dominant_kernel(model, device, inputs, reps=20):
-    """attn_sparse_kernel (largest share of kernel time in the rocprofv3 trace of this command): the masked epipolar
-    attention of the 5 + 5 temporal blocks at 32x32 and 16x16 latents of one CFG step (b = 2: cond + uncond), on the
-    benchmark clip's own masks, timed with HIP events on the launch stream: once in isolation (a hipGraph of those 10
+    """The masked epipolar attention (largest share of kernel time in the rocprofv3 trace of this command; round 4: attn_shared_kernel<4,4>,
+    K / V blocks shared by a workgroup): the 5 + 5 temporal blocks at 32x32 and 16x16 latents of one CFG step (b = 2: cond + uncond), on
+    the benchmark clip's own masks, timed with HIP events on the launch stream: once in isolation (a hipGraph of those 10
     launches, warm caches: `us_per_launch_isolated`) and once inside eager CFG steps of the model (`us_per_launch`, the
     figure the roofline uses and the one the rocprofv3 trace of this command agrees with).
     Algorithmic FLOPs per launch by SURVEY.md section 8(d)'s dense convention (4 Lq Lk 64 H b, mask ignored), and the
-    executed share (32-key blocks the kernel visits / all blocks) beside it."""
+    executed share ((32-query, 32-key) half-blocks the kernel multiplies / all) beside it."""
     from camc2v_amd import ops
+    if not WORKLOAD["camera"]:
+        return None
+    T = WORKLOAD["T"]
     cam = inputs[0]["camera_condition"]["sample_locs_packed"]
     g = torch.Generator(device=device).manual_seed(SEED)
-    calls, flops, visited = [], [], []
+    shared = os.environ.get("CCV_ATTN_SHARED", "4") in ("4", "8")
+    calls, flops, visited, executed = [], [], [], []
     for d, hl, H in ((8, 32, 5), (16, 16, 10)):
         bits, flags, perm, wbits, order = cam[d]
-        L = 16 * hl * hl
+        L = T * hl * hl
         qkv = torch.randn(2 * L, 3 * H * 64, device=device, generator=g).to(torch.bfloat16)
         kreg = torch.randn(4, H * 64, device=device, generator=g).to(torch.bfloat16)
         s = (L * 3 * H * 64, 0, 3 * H * 64)
@@ -259,10 +358,9 @@ def dominant_kernel(model, device, inputs, reps=20):
                   wave_bits=wbits, group_order=order, perm=perm, kreg=kreg, vreg=kreg, out=out, o_str=(L * H * 64, 0, H * 64))
         calls.append((qkv, H, kw))
         flops.append(4.0 * L * L * 64 * H * 2)
-        nblk = (L + 31) // 32
-        words = wbits.reshape(-1).to(torch.int64) & 0xFFFFFFFF
-        pop = sum(int(((words >> i) & 1).sum()) for i in range(32))
-        visited.append(pop / (wbits.shape[0] * wbits.shape[1] * nblk))
+        v64, h32 = _block_fractions(bits, wbits, L)
+        visited.append(v64)
+        executed.append(h32 if shared and (L + 31) // 32 <= 1037 else v64)
 
     def run():
         for qkv, H, kw in calls:
@@ -288,14 +386,11 @@ def dominant_kernel(model, device, inputs, reps=20):
     # runs), HIP events on the launch stream around every sparse-attention launch (ops.SPARSE_PROBE); the first step is warm-up.
     # This is the figure the roofline uses -- K / V come fresh from the QKV projection and the other layers' traffic has passed
     # through the caches in between, as in the profiled run.
-    cond, uncond, fs, x_T, _ = inputs
-    t = torch.full((x_T.shape[0],), 439, dtype=torch.long, device=device)
-    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True))
     ops.SPARSE_PROBE = probe = []
     try:
         with torch.no_grad():
             for _ in range(3):
-                model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)
+                cfg_step(model, device, inputs)
         torch.cuda.synchronize()
     finally:
         ops.SPARSE_PROBE = None
@@ -303,14 +398,16 @@ def dominant_kernel(model, device, inputs, reps=20):
     timed = probe[per_step:]
     us = sum(a.elapsed_time(b) for a, b, *_ in timed) * 1e3 / max(1, len(timed)) if timed else us_isolated
     fl = 0.5 * (flops[0] + flops[1])                  # mean over the 10 launches
-    fl_exec = 0.5 * (flops[0] * visited[0] + flops[1] * visited[1])
+    fl_exec = 0.5 * (flops[0] * executed[0] + flops[1] * executed[1])
     tf = fl / us / 1e6
-    return dict(kernel="attn_sparse_kernel", us_per_launch=us, us_per_launch_isolated=us_isolated, launches_timed_in_model=len(timed),
+    kernel = "attn_shared_kernel<4,4>" if shared else "attn_sparse_kernel"
+    return dict(kernel=kernel, us_per_launch=us, us_per_launch_isolated=us_isolated, launches_timed_in_model=len(timed),
                 flops_per_launch=fl, achieved_dense=tf, frac_dense=tf / PEAK_BF16_TFLOPS,
                 executed_fraction=fl_exec / fl, effective_tflops=fl_exec / us / 1e6,
-                problem="masked epipolar attention, b=2 (cond+uncond), L=16384 H=5 (x5) and L=4096 H=10 (x5) per CFG step, 4 register "
+                problem=f"masked epipolar attention, b=2 (cond+uncond), L={T * 1024} H=5 (x5) and L={T * 256} H=10 (x5) per CFG step, 4 register "
                         "tokens, benchmark masks; dense FLOP convention 4 Lq Lk 64 H b",
-                visited_block_fraction={"32x32": visited[0], "16x16": visited[1]})
+                visited_block_fraction={"32x32": visited[0], "16x16": visited[1]},
+                executed_halfblock_fraction={"32x32": executed[0], "16x16": executed[1]})
 
 
 def gemm_family(model, device, inputs, steps=2):
@@ -319,16 +416,13 @@ def gemm_family(model, device, inputs, steps=2):
     steps of the benchmark clip (`ops.GEMM_PROBE`; one warm-up step, `steps` timed).  FLOPs = sum of 2 M N K taps of the calls,
     i.e. executed work (context K/V projections are cached per clip and do not appear)."""
     from camc2v_amd import ops
-    cond, uncond, fs, x_T, _ = inputs
-    t = torch.full((x_T.shape[0],), 439, dtype=torch.long, device=device)
-    uc = dict(uncond, camera_condition=dict(cond["camera_condition"], is_uc=True))
     with torch.no_grad():
-        model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)      # warm-up (caches, allocator)
+        cfg_step(model, device, inputs)      # warm-up (caches, allocator)
         torch.cuda.synchronize()
         ops.GEMM_PROBE = probe = []
         try:
             for _ in range(steps):
-                model.apply_model_pair(x_T, t, cond, uc, fs=fs, enable_camera_condition=True)
+                cfg_step(model, device, inputs)
             torch.cuda.synchronize()
         finally:
             ops.GEMM_PROBE = None
@@ -336,7 +430,7 @@ def gemm_family(model, device, inputs, steps=2):
     tf = sum(f for _, _, f in probe) / steps / 1e12
     return dict(calls_per_cfg_step=len(probe) // steps, ms_per_cfg_step=ms, executed_tflop_per_cfg_step=tf, achieved=tf / ms * 1e3,
                 frac=tf / ms * 1e3 / PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                note="every ccv_gemm call of one eager CFG step (b = 2), HIP events on the launch stream; the events' own cost "
+                note="every ccv_gemm call of one eager sampler step (b = 2 under CFG), HIP events on the launch stream; the events' own cost "
                      "(~1 us per call) is inside the figure")
 
 
@@ -353,36 +447,41 @@ def two_clips_per_forward(model, device, use_graph, rank=0, calls=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / calls
     assert torch.isfinite(out).all()
-    return {"frames_per_s": 32.0 / dt, "ms_per_call": 1e3 * dt, "clips_per_call": 2,
+    return {"frames_per_s": 2.0 * WORKLOAD["T"] / dt, "ms_per_call": 1e3 * dt, "clips_per_call": 2,
             "note": "two independent clips per sampling call (own conditioning each); not the metric's configuration"}
 
 
 def skipped_flops(inputs):
-    """TFLOP per clip that the reference's dense count (375) contains and this path does not execute: the masked-out 32-key
-    blocks of the epipolar attention (counted from the clip's own block bitmaps) and the per-step, per-frame context K/V
-    projections (done once per clip here)."""
-    cam = inputs[0]["camera_condition"]["sample_locs_packed"]
+    """TFLOP per clip that the reference's dense count contains and this path does not execute: the masked-out (32-query, 32-key)
+    half-blocks of the epipolar attention (counted from the clip's own masks) and the per-step, per-frame context K/V projections
+    (done once per clip here)."""
+    w = WORKLOAD
+    T = w["T"]
     epi = 0.0
-    for d, hl, H, nblocks in ((8, 32, 5, 5), (16, 16, 10, 5), (32, 8, 20, 5), (64, 4, 20, 1)):
-        wbits = cam[d][3]
-        L = 16 * hl * hl
-        words = wbits.reshape(-1).to(torch.int64) & 0xFFFFFFFF
-        pop = sum(int(((words >> i) & 1).sum()) for i in range(32))
-        frac = pop / (wbits.shape[0] * wbits.shape[1] * ((L + 31) // 32))
-        if hl <= 8:
-            frac = 1.0            # small maps run the tiled masked kernel (128x64 tile skipping only): counted as dense
-        epi += nblocks * 4.0 * L * L * 64 * H * (1.0 - frac)
-    epi_clip = epi * 2 * 25 / 1e12                      # both CFG halves, 25 steps
+    if w["camera"]:
+        cam = inputs[0]["camera_condition"]["sample_locs_packed"]
+        shared = os.environ.get("CCV_ATTN_SHARED", "4") in ("4", "8")
+        for d, hl, H, nblocks in ((8, 32, 5, 5), (16, 16, 10, 5), (32, 8, 20, 5), (64, 4, 20, 1)):
+            L = T * hl * hl
+            v64, h32 = _block_fractions(cam[d][0], cam[d][3], L)
+            frac = h32 if shared and (L + 31) // 32 <= 1037 else v64
+            if hl <= 8:
+                frac = 1.0            # small maps run the tiled masked kernel (128x64 tile skipping only): counted as dense
+            epi += nblocks * 4.0 * L * L * 64 * H * (1.0 - frac)
+    passes = 2 if w["uncond_ctx"] else 1
+    epi_clip = epi * passes * 25 / 1e12
     sum_c = 5 * 320 + 5 * 640 + 6 * 1280                # the 16 cross-attention layers' widths
-    kv_ref = 25 * sum(4.0 * 16 * L * 1024 * sum_c for L in (77 + 256 * (1 + N_CONTEXT), 77 + 256)) / 1e12
-    kv_here = (4.0 * (77 + 256 * (1 + N_CONTEXT)) * 1024 * sum_c + 4.0 * (77 + 16 * 16) * 1024 * sum_c) / 1e12
+    ctxs = [w["cond_ctx"]] + ([w["uncond_ctx"]] if w["uncond_ctx"] else [])
+    per_frame_tokens = lambda L: (77 + 16) if L == 77 + 16 * T else L      # reference context rule (openaimodel3d.py:575)
+    kv_ref = 25 * sum(4.0 * T * per_frame_tokens(L) * 1024 * sum_c for L in ctxs) / 1e12
+    kv_here = sum(4.0 * L * 1024 * sum_c for L in ctxs) / 1e12
     return epi_clip, kv_ref - kv_here
 
 
 def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None, skipped=None, ranks_seen=None, lanes=1, sharded=False, gemm=None):
-    from camc2v_amd import configs
+    w = WORKLOAD
     clips = steps if sharded else steps * world          # frame-sharded: the ranks sample each clip TOGETHER
-    tf_per_clip = 25 * (configs.TFLOP_COND_N2 + configs.TFLOP_UNCOND_CAM)
+    tf_per_clip = workload_tflop_per_clip(w)
     per_clip_s = (dev_ms / 1e3 / steps) if dev_ms is not None else elapsed / steps
     achieved = tf_per_clip / per_clip_s  # one GPU's rate: algorithmic TFLOP of a clip / its device time
     whole = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
@@ -413,17 +512,20 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
             pass
     if gemm is not None:
         roof["gemm_family"] = gemm
+        if dom is None:      # no masked attention in this workload: the GEMM family (linear layers + implicit-GEMM convolutions) dominates
+            roof.update(achieved=gemm["achieved"], frac=gemm["frac"], kernel="ccv_gemm family (gemm_dma / gemm_ring / gemm_astat kernels)",
+                        problem="every ccv_gemm launch of one sampler step, executed FLOPs / their summed device time")
     roof["whole_path"] = whole
     line = {
-        "metric": "denoised video frames/sec at 16x256x256, 25 DDIM steps, CFG=7.5",
-        "value": 16.0 * clips / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "metric": w["metric"],
+        "value": float(w["T"]) * clips / elapsed, "unit": "frames/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "CamContextI2V-256 (camera + 2 context frames), 1 clip x 16 frames x 256x256 per GPU, "
-                               "25 DDIM steps, CFG 7.5, guidance_rescale 0.7, eta 1.0; seeded N(0,0.02) weights; every clip "
+        "config": {"workload": w["label"] + "; seeded N(0,0.02) weights; every clip "
                                "has its own conditioning tensors (per-clip prologue inside the timed region); every sampling call "
                                "is ONE clip (UNet batch 2 under CFG) -- clips_in_flight_per_gpu independent calls run on "
                                "their own HIP streams at a time",
+                   "baseline_config": WORKLOAD_KEY,
                    "clips_per_gpu": 1, "clips_in_flight_per_gpu": lanes, "parallelism": (sharded if isinstance(sharded, str) else f"frame-shard{world}") if sharded else f"clip-dp{world}",
                    "launch": "hipGraph" if use_graph else "eager"},
         "roofline": roof,
@@ -473,7 +575,11 @@ def main(argv=None, hooks=None):
     ap.add_argument("--shard-graph", action="store_true", help="with --frame-shard on RCCL: capture the sharded step, collectives included, "
                     "into a hipGraph (the exchanges are issued on the compute stream); untested until a multi-GPU node is reachable")
     ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="c1", help="BASELINE.json configs: c1 (default, the metric's configuration: "
+                    "CamContextI2V CFG 7.5), c0 (DynamiCrafter, CFG off), c3 (CamI2V baseline), c4 (32 frames, CFG 3.5)")
     args = ap.parse_args(argv)
+    global WORKLOAD, WORKLOAD_KEY
+    WORKLOAD, WORKLOAD_KEY = WORKLOADS[args.config], args.config
     hooks = hooks or {}
 
     if "WORLD_SIZE" not in os.environ:
@@ -584,8 +690,9 @@ def main(argv=None, hooks=None):
                 run_clip(model, *sets[(args.warmup + i) % n_sets], use_graph)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 2
-            line["config"]["one_clip_at_a_time"] = {"frames_per_s": 16.0 / dt, "ms_per_clip": 1e3 * dt}
-        if world == 1 and extras:
+            line["config"]["one_clip_at_a_time"] = {"frames_per_s": float(WORKLOAD["T"]) / dt, "ms_per_clip": 1e3 * dt}
+            line["value_one_clip_at_a_time"] = float(WORKLOAD["T"]) / dt
+        if world == 1 and extras and args.config == "c1":
             line["config"]["two_clips_per_forward"] = two_clips_per_forward(model, device, use_graph, rank)
         if world == 1 and extras and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_full_size"] = cpu_baseline(model, device, sets[0])

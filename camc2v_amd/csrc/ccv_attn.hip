@@ -1024,25 +1024,29 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
 // seeded S^T = K Q^T, in-lane softmax, O^T += V^T P^T.  Items (batch-head slice, query group) come from the same persistent
 // queue, longest first by p.wg_order (ccv_attn_group_order_merged).
 // =================================================================================================
+constexpr int SHARED_MAX_BLOCKS = 1037;  // schedule entries (16 bits each) per item kept in LDS: Lk <= 32 * 1037 (+ the register-token step)
+
 template <int NW, int S>
 __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-    static_assert(S >= 3 && S <= 6, "ring depth");
+    static_assert(S >= 3 && S <= 5, "ring depth");
     constexpr int RING = S * 8192, MWB = NW * S * 256;
     constexpr int PP = 8 / NW;          // K / V pieces per wave and block
     constexpr int P = PP + 1;           // + the wave's mask words: vector-memory operations per wave and block
     constexpr int GQ = NW * 32;         // queries per item
-    constexpr int DONE = 0x7fffffff;
-    __shared__ __attribute__((aligned(256))) unsigned char sm[RING + MWB + 256 + 16];   // ring | mask words [wave][stage][64] | seed table | item
+    constexpr int SCHED = RING + MWB + 256 + 16;                    // the item's schedule: 16 bits per step
+    __shared__ __attribute__((aligned(256))) unsigned char sm[SCHED + 2 * (SHARED_MAX_BLOCKS + 3)];   // ring | mask words [wave][stage][64] | seed table | item, n | schedule
     static_assert((RING + MWB) % 256 == 0, "seed table offset must keep the low 8 address bits clear");
     float* seed_lut = reinterpret_cast<float*>(sm + RING + MWB);
-    volatile unsigned int* item_word = reinterpret_cast<volatile unsigned int*>(sm + RING + MWB + 256);
+    unsigned int* item_word = reinterpret_cast<unsigned int*>(sm + RING + MWB + 256);   // [0] item, [1] steps of the item
+    uint16_t* sched = reinterpret_cast<uint16_t*>(sm + SCHED);   // (plain LDS accesses: a volatile generic pointer becomes flat_load + vmcnt(0))
     const int tid = threadIdx.x;
     if (tid < 64) seed_lut[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 0.f : NEG_INF;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    const int hh4 = 4 * hh;
     const float sl2 = p.scale * 1.4426950408889634f;
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_attn_zero_line);
     unsigned char* mwring = sm + RING + wave * (S * 256);
@@ -1050,15 +1054,18 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     const int ngroups = (p.Lq + GQ - 1) / GQ;
     const int ngroups64 = (p.Lq + 63) >> 6;
     const int nbh = p.B * p.H;
-    const int k_ls32 = (int)p.k_ls, v_ls32 = (int)p.v_ls;
     const int ppr_ = p.perm_w >> 3;
     const bool perm_pow2 = p.perm_w && (p.perm_hw & (p.perm_hw - 1)) == 0 && (ppr_ & (ppr_ - 1)) == 0;
     const int sh_hw = perm_pow2 ? __builtin_ctz(p.perm_hw) : 0, sh_ppr = perm_pow2 ? __builtin_ctz(ppr_) : 0;
     const long qitems = (long)nbh * ngroups;
     const int lr8 = lane >> 3, pc = lane & 7;
+    // this wave's pieces of a block (piece id = wave * PP + t; ids 0-3 are the four 8-row pieces of K, 4-7 those of V) are all K or all V
+    const bool wave_k = wave * PP < 4;
+    const int ls32 = wave_k ? (int)p.k_ls : (int)p.v_ls;      // token stride of the operand this wave stages
     // per-lane LDS addresses of stage 0 (see compute): seed table, the four K fragments, the two V^T read bases (read_vt_block's layout)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(sm);
     const uint32_t lut_addr = lds0 + RING + MWB;
+    const uint32_t mw_addr = lds0 + RING + wave * (S * 256) + 4 * r;
     uint32_t ka[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) ka[s] = lds0 + r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
@@ -1071,12 +1078,21 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
         va0 = lds0 + row0 * 128 + c + x;
         va1 = lds0 + row0 * 128 + c + 64 - x;
     }
+    int poff32[PP];     // per-lane byte offsets of this wave's pieces inside a block (fixed for the whole launch)
+#pragma unroll
+    for (int t = 0; t < PP; ++t) {
+        const int j = (wave * PP + t) & 3;
+        const int rowin = 8 * j + lr8;
+        const long step = p.perm_w ? (long)j * p.perm_w + lr8 : (long)rowin;
+        const int swz = wave_k ? ((pc ^ ((rowin >> 1) & 7)) << 3) : ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
+        poff32[t] = (int)(step * ls32 + swz) * 2;
+    }
 
   for (;;) {
-    __syncthreads();   // everybody is done with the previous item: the ring, the mask words and the item word are free
-    if (tid == 0) *item_word = atomicAdd(p.queue_counters ? p.queue_counters : &g_sparse_ctr[p.slot][0], 1u);
+    __syncthreads();   // everybody is done with the previous item: the ring, the mask words, the schedule and the item word are free
+    if (tid == 0) item_word[0] = atomicAdd(p.queue_counters ? p.queue_counters : &g_sparse_ctr[p.slot][0], 1u);
     __syncthreads();
-    const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)*item_word);
+    const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)item_word[0]);
     if (item >= qitems) break;
     const int rank = (int)(item / nbh), bh = (int)(item % nbh);
     const int head = bh % p.H, b = bh / p.H;
@@ -1086,6 +1102,36 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     const int q0w = qg * GQ + 32 * wave;          // this wave's 32 queries
     const bool wave_active = q0w < p.Lq;
 
+    // ---- the item's schedule, built once by wave 0 into LDS: step -> block + 1 (0 = register tokens), the set bits of the OR of the
+    // item's bitmap rows in ascending order.  Lane l expands word l.
+    if (wave == 0) {
+        uint32_t u = 0u;
+        const uint32_t* wrow = p.wave_bits + (long)mb * p.wave_bs;
+#pragma unroll
+        for (int j = 0; j < NW / 2; ++j) {
+            const int g64 = qg * (NW / 2) + j;
+            if (g64 < ngroups64 && lane < p.wave_words) u |= wrow[(long)g64 * p.wave_words + lane];
+        }
+        const int cnt = __popc(u);
+        int pre = cnt;                                // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += t;
+        }
+        const int total = __shfl(pre, 63, 64);
+        int at = pre - cnt + (has_reg ? 1 : 0);
+        if (lane == 0) {
+            if (has_reg) sched[0] = (uint16_t)0;
+            item_word[1] = (unsigned int)(total + (has_reg ? 1 : 0));
+        }
+        while (u) {
+            const int bit = __builtin_ctz(u);
+            u &= u - 1;
+            sched[at++] = (uint16_t)(lane * 32 + bit + 1);
+        }
+    }
+
     bf16x8 qf[4];
     {
         const int qi = min(q0w + r, p.Lq - 1);
@@ -1093,90 +1139,50 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
-    const uint16_t* kmain = p.k + bo * p.k_bso + bi * p.k_bsi + head * 64;
-    const uint16_t* vmain = p.v + bo * p.v_bso + bi * p.v_bsi + head * 64;
-
-    // ---- block schedule (identical in every wave): -1 = register tokens, then the set bits of the OR of the item's bitmap rows ----
-    uint32_t my_word = 0u;
-    {
-        const uint32_t* wrow = p.wave_bits + (long)mb * p.wave_bs;
-#pragma unroll
-        for (int j = 0; j < NW / 2; ++j) {
-            const int g64 = qg * (NW / 2) + j;
-            if (g64 < ngroups64 && lane < p.wave_words) my_word |= wrow[(long)g64 * p.wave_words + lane];
-        }
-    }
-    int widx = -1;
-    uint32_t cbits = 0;
-    bool reg_pending = has_reg;
-    auto next_block = [&]() -> int {
-        if (reg_pending) { reg_pending = false; return -1; }
-        while (cbits == 0) {
-            if (++widx >= p.wave_words) { widx = p.wave_words; return DONE; }
-            cbits = (uint32_t)__builtin_amdgcn_readlane((int)my_word, widx);
-        }
-        const int bit = __builtin_ctz(cbits);
-        cbits &= cbits - 1;
-        return widx * 32 + bit;
-    };
-
-    // this wave's pieces of a block: piece id = wave * PP + t; ids 0-3 are the four 8-row pieces of K, 4-7 those of V
-    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kmain), 0, ((p.Lk - 1) * k_ls32 + 64) * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vmain), 0, ((p.Lk - 1) * v_ls32 + 64) * 2, 0x00020000);
+    // buffer descriptors over the operand slice this wave stages (K or V of this batch and head) and over the mask rows
+    const uint16_t* opnd = (wave_k ? p.k + bo * p.k_bso + bi * p.k_bsi : p.v + bo * p.v_bso + bi * p.v_bsi) + head * 64;
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(opnd), 0, ((p.Lk - 1) * ls32 + 64) * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.mask_bits + (long)mb * p.mask_bs), 0, p.Lq * p.mask_words * 4, 0x00020000);
-    int poff32[PP];
-#pragma unroll
-    for (int t = 0; t < PP; ++t) {
-        const int pid = wave * PP + t, j = pid & 3;
-        const bool isk = pid < 4;
-        const int rowin = 8 * j + lr8;
-        const long step = p.perm_w ? (long)j * p.perm_w + lr8 : (long)rowin;
-        const int swz = isk ? ((pc ^ ((rowin >> 1) & 7)) << 3) : ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
-        poff32[t] = (int)(step * (isk ? p.k_ls : p.v_ls) + swz) * 2;
-    }
     const int moff32 = min(q0w + r, p.Lq - 1) * p.mask_words * 4;   // both half-waves fetch the 32 words (lane l <-> query q0w + (l & 31))
+    const uint16_t* regsrc = nullptr;
+    if (has_reg) regsrc = (wave_k ? p.kreg : p.vreg) + head * 64;
 
-    auto issue = [&](int blk, int stage) __attribute__((always_inline)) {
-        unsigned char* sK = sm + stage * 8192;
+    // e = schedule entry; stage = ring slot
+    auto issue = [&](uint32_t e, int stage) __attribute__((always_inline)) {
+        unsigned char* dst = sm + stage * 8192 + wave * (PP * 1024);
+        const int blk = (int)(e & 0xffffu) - 1;
         if (blk < 0) {   // register tokens: rows >= nreg read the zero line
 #pragma unroll
             for (int t = 0; t < PP; ++t) {
-                const int pid = wave * PP + t, j = pid & 3;
-                const bool isk = pid < 4;
+                const int j = (wave * PP + t) & 3;
                 const int rowin = 8 * j + lr8;
-                const bool ok = rowin < p.nreg;
-                const int swz = isk ? ((pc ^ ((rowin >> 1) & 7)) << 3) : ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
-                const uint16_t* g = ok ? (isk ? p.kreg : p.vreg) + (long)rowin * p.H * 64 + head * 64 + swz : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(sK + pid * 1024), 16, 0, 0);
+                const int swz = wave_k ? ((pc ^ ((rowin >> 1) & 7)) << 3) : ((pc ^ (((rowin >> 1) & 1) << 2)) << 3);
+                const uint16_t* g = rowin < p.nreg ? regsrc + (long)rowin * p.H * 64 + swz : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(dst + t * 1024), 16, 0, 0);
             }
         } else {
             const int k0 = 32 * blk;
             int base = k0;
-            if (p.perm_w) {
+            if (p.perm_w) {   // first stored row of the 4x8-pixel patch (wave-uniform scalar arithmetic)
                 int f, patch, py, px;
                 if (perm_pow2) {
                     f = k0 >> sh_hw;
                     patch = (k0 & (p.perm_hw - 1)) >> 5;
                     py = patch >> sh_ppr;
-                    px = patch & ((p.perm_w >> 3) - 1);
+                    px = patch & (ppr_ - 1);
                 } else {
                     f = k0 / p.perm_hw;
                     patch = (k0 - f * p.perm_hw) >> 5;
-                    const int ppr = p.perm_w >> 3;
-                    py = patch / ppr;
-                    px = patch - py * ppr;
+                    py = patch / ppr_;
+                    px = patch - py * ppr_;
                 }
                 base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
             }
+            const int so = base * ls32 * 2;
 #pragma unroll
-            for (int t = 0; t < PP; ++t) {
-                const int pid = wave * PP + t;
-                if (pid < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lptr_t*)(sK + pid * 1024), 16, poff32[t], base * k_ls32 * 2, 0, 0);
-                else         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_t*)(sK + pid * 1024), 16, poff32[t], base * v_ls32 * 2, 0, 0);
-            }
+            for (int t = 0; t < PP; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_o, (lptr_t*)(dst + t * 1024), 16, poff32[t], so, 0, 0);
         }
-        const int wi = blk < 0 ? 0 : blk;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (lptr_t*)(mwring + stage * 256), 4, moff32, wi * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (lptr_t*)(mwring + stage * 256), 4, moff32, max(blk, 0) * 4, 0, 0);
     };
 
     float m_run = NEG_INF, l_run = 0.f;
@@ -1187,22 +1193,22 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
 
     // every LDS address of the loop is a per-lane constant of stage 0 + an immediate offset (stage * 8192 ...): one set of address
-    // registers for all S stages
-    auto compute = [&](int blk, auto stc) __attribute__((always_inline)) {
+    // registers for all S stages.  mw = the wave's mask words of the block (already waited for).
+    auto compute = [&](int blk, uint32_t mw_raw, auto stc) __attribute__((always_inline)) {
         constexpr int stage = decltype(stc)::value;
         constexpr int KO = stage * 8192, VO = stage * 8192 + 4096;
         const int left = blk < 0 ? p.nreg : min(32, p.Lk - 32 * blk);
         const uint32_t lim = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
-        const uint32_t* wl = reinterpret_cast<const uint32_t*>(mwring + stage * 256);
-        const uint32_t mw = (blk < 0 ? 0xffffffffu : wl[r]) & lim;
+        const uint32_t mw = (blk < 0 ? 0xffffffffu : mw_raw) & lim;
         if (!wave_active || __ballot(mw != 0u) == 0ull) return;
         f32x16 sa;
         {
             uint32_t ad[4];
+            const uint32_t mwsh = mw >> hh4;            // the half-wave's nibbles at bits 0, 8, 16, 24 (constant bit offsets: no offset registers)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 uint32_t n0;
-                asm("v_bfe_u32 %0, %1, %2, 4" : "=v"(n0) : "v"(mw), "v"(8 * g4 + 4 * hh));
+                asm("v_bfe_u32 %0, %1, %2, 4" : "=v"(n0) : "v"(mwsh), "n"(8 * g4));
                 asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(ad[g4]) : "v"(n0), "v"(lut_addr));
             }
             f32x4 t0, t1, t2, t3;
@@ -1264,40 +1270,51 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     // retire the ordinary vector loads where hipcc can see it (see attn_sparse_kernel)
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) asm volatile("" ::"v"(qf[s4]));
-    asm volatile("" ::"v"(my_word));
 
-    // ---- S-deep ring: blocks fifo[0] (current) .. fifo[S-2] are in flight or landed ----
-    int fifo[S - 1];
+    __syncthreads();                                   // the schedule is complete
+    const int n = (int)__builtin_amdgcn_readfirstlane((int)item_word[1]);
+
+    // ---- S-deep ring: steps i .. i+S-2 are in flight or landed while step i is multiplied ----
+    int cur_blk[S - 1];                                // block ids of steps i .. i+S-2 (scalars)
 #pragma unroll
     for (int j = 0; j < S - 1; ++j) {
-        fifo[j] = next_block();
-        if (fifo[j] != DONE) issue(fifo[j], j);
+        cur_blk[j] = -2;
+        if (j < n) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[j]);
+            cur_blk[j] = (int)(e & 0xffffu) - 1;
+            issue(e, j);
+        }
     }
+    const uint32_t sched_addr = lds0 + SCHED;
+    uint32_t e_next;                                    // entry of the step the next iteration issues (prefetched one step ahead)
+    asm volatile("ds_read_u16 %0, %1" : "=v"(e_next) : "v"(sched_addr + 2 * min(S - 1, n - 1)) : "memory");
+    int i = 0;
     auto step = [&](auto stc) __attribute__((always_inline)) -> bool {
         constexpr int st = decltype(stc)::value;
-        const int cur = fifo[0];
-        if (cur == DONE) return false;
-        // my own pieces of `cur` have landed when at most the operations of the blocks behind it are outstanding
-        if (fifo[S - 2] != DONE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * P) : "memory");
-        else {
-            bool waited = false;
-#pragma unroll
-            for (int a = S - 3; a >= 1; --a)
-                if (!waited && fifo[a] != DONE) {
-                    waited = true;
-                    if (a == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * P) : "memory");
-                    if (a == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-                    if (a == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * P) : "memory");
-                }
-            if (!waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (i >= n) return false;
+        // my own pieces of step i have landed when at most the operations of the steps behind it are outstanding
+        const int behind = n - 1 - i;                 // steps after this one
+        if (behind >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * P) : "memory");
+        else if (S > 3 && behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * P) : "memory");
+        else if (S > 4 && behind == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int nb = next_block();
-        if (nb != DONE) issue(nb, (st + S - 1) % S);
-        compute(cur, stc);
+        // the mask words of this step first: their LDS latency runs under the issue of step i + S - 1
+        uint32_t mw_raw;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(mw_raw) : "v"(mw_addr), "n"(st * 256) : "memory");
+        int nblk = -2;
+        if (i + S - 1 < n) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_next);
+            nblk = (int)(e & 0xffffu) - 1;
+            issue(e, (st + S - 1) % S);
+            asm volatile("ds_read_u16 %0, %1" : "=v"(e_next) : "v"(sched_addr + 2 * min(i + S, n - 1)) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mw_raw), "+v"(e_next)::"memory");
+        compute(cur_blk[0], mw_raw, stc);
 #pragma unroll
-        for (int j = 0; j < S - 2; ++j) fifo[j] = fifo[j + 1];
-        fifo[S - 2] = nb;
+        for (int j = 0; j < S - 2; ++j) cur_blk[j] = cur_blk[j + 1];
+        cur_blk[S - 2] = nblk;
+        ++i;
         return true;
     };
     for (;;) {
@@ -1307,7 +1324,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
         if (go) go = step(std::integral_constant<int, 2>{});
         if constexpr (S > 3) { if (go) go = step(std::integral_constant<int, 3>{}); }
         if constexpr (S > 4) { if (go) go = step(std::integral_constant<int, 4>{}); }
-        if constexpr (S > 5) { if (go) go = step(std::integral_constant<int, 5>{}); }
         if (!go) break;
     }
 
@@ -1528,9 +1544,10 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             a.scale = p.scale; a.slot = slot; a.use_xcd_queues = xcd_queues;
             a.wg_order = nullptr; a.wg_order_bs = 0;
             // round 4: K / V blocks shared by the workgroup (attn_shared_kernel).  variant 4 / 5 force the 8- / 4-wave form, variant 6 the
-            // per-wave kernel; otherwise CCV_ATTN_SHARED = 8 (default) | 4 | 0 (A/B aid)
-            static const int shared_env = [] { const char* e = getenv("CCV_ATTN_SHARED"); const int v = e ? atoi(e) : 8; return (v == 8 || v == 4) ? v : 0; }();
-            const int nw = p.variant == 4 ? 8 : (p.variant == 5 ? 4 : (p.variant == 6 ? 0 : shared_env));
+            // per-wave kernel; otherwise CCV_ATTN_SHARED = 4 (default: measured fastest, profiles/r04_sparse_shared_kv.txt) | 8 | 0 (A/B aid)
+            static const int shared_env = [] { const char* e = getenv("CCV_ATTN_SHARED"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 4) ? v : 0; }();
+            int nw = p.variant == 4 ? 8 : (p.variant == 5 ? 4 : (p.variant == 6 ? 0 : shared_env));
+            if ((p.Lk + 31) / 32 > SHARED_MAX_BLOCKS) nw = 0;   // the item's schedule lives in LDS (16 bits per step): longer key sequences stay on the per-wave kernel
             if (nw) {
                 const int merge = nw / 2;                         // 64-query groups per item
                 const long g64 = (p.Lq + 63) / 64, items_per = (g64 + merge - 1) / merge;
@@ -1541,8 +1558,16 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
                 const long items = items_per * p.H * p.B;
                 const long cap_s = pct * n_cu / 100 * (nw == 8 ? 1 : 2);   // 2 x 512 or 4 x 256 threads per CU
                 const long wgs_s = items < cap_s ? items : cap_s;
-                if (nw == 8) hipLaunchKernelGGL((attn_shared_kernel<8, 4>), dim3((unsigned)wgs_s), dim3(512), 0, st, a);
-                else         hipLaunchKernelGGL((attn_shared_kernel<4, 4>), dim3((unsigned)wgs_s), dim3(256), 0, st, a);
+                static const int ring_s = [] { const char* e = getenv("CCV_ATTN_SHARED_S"); const int v = e ? atoi(e) : 4; return (v >= 3 && v <= 5) ? v : 4; }();   // ring depth (A/B aid)
+                if (nw == 8) {
+                    if (ring_s == 3)      hipLaunchKernelGGL((attn_shared_kernel<8, 3>), dim3((unsigned)wgs_s), dim3(512), 0, st, a);
+                    else if (ring_s == 5) hipLaunchKernelGGL((attn_shared_kernel<8, 5>), dim3((unsigned)wgs_s), dim3(512), 0, st, a);
+                    else                  hipLaunchKernelGGL((attn_shared_kernel<8, 4>), dim3((unsigned)wgs_s), dim3(512), 0, st, a);
+                } else {
+                    if (ring_s == 3)      hipLaunchKernelGGL((attn_shared_kernel<4, 3>), dim3((unsigned)wgs_s), dim3(256), 0, st, a);
+                    else if (ring_s == 5) hipLaunchKernelGGL((attn_shared_kernel<4, 5>), dim3((unsigned)wgs_s), dim3(256), 0, st, a);
+                    else                  hipLaunchKernelGGL((attn_shared_kernel<4, 4>), dim3((unsigned)wgs_s), dim3(256), 0, st, a);
+                }
             } else
             hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
         }

@@ -776,7 +776,7 @@ class MaskPack(tuple):
         return self
 
 
-WG_MERGE = 4   # 64-query groups per item of the workgroup-shared sparse kernel's default form (8 waves x 32 queries)
+WG_MERGE = 2   # 64-query groups per item of the workgroup-shared sparse kernel's default form (4 waves x 32 queries)
 
 
 def attn_group_order(wave_bits, merged=True):

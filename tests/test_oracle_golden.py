@@ -362,3 +362,22 @@ def test_oracle_sampler_follows_reference_25_step_trajectory(golden_dir):
     sd_plain = {k: v for k, v in sd.items() if ".pluker_projection." not in k and ".epipolar." not in k}
     assert len(sd_plain) == int(fx["dc_num_keys"])
     run("dc", "noise_seed_dc", eps(inp["ctx_pf"], None, sd_plain), None, 1.0, 0.0)
+
+
+def test_per_op_oracle_vs_reference_module_fixtures(golden_dir):
+    """every op of the hot path, restated in oracle/unet_oracle.py, against the output of the REFERENCE'S OWN
+    module on the same seeded weights and inputs (tests/golden/ops_medium.npz, oracle/gen_golden_ops.py): GroupNorm32, LayerNorm,
+    ResBlock (+ TemporalConvBlock), TemporalConvBlock, Down / Upsample, SpatialTransformer, self / cross attention with 77, 77 + 16 and
+    77 + 768 context tokens, GEGLU feed-forward, the camera-patched TemporalTransformer (both add_types, Pluecker features, epipolar
+    mask), Epipolar at Lq = 1024 and 256 with register tokens, masked and unmasked."""
+    from oracle import ops_fixture
+    fx, sd, inp, masks = ops_fixture.load(golden_dir)
+    got = ops_fixture.oracle_outputs(sd, inp, masks)
+    ys = [k for k in fx if not k.startswith(("checksum_", "mask_")) and k not in ("F64", "perturb_noise")]
+    assert sorted(ys) == sorted(got), (sorted(ys), sorted(got))
+    for k in ys:
+        a, b = got[k], torch.from_numpy(fx[k])
+        assert tuple(a.shape) == tuple(b.shape), k
+        err = ((a - b).norm() / b.norm()).item()
+        assert err <= 2e-5, f"{k}: rel-L2 {err:.3e}"
+        _close(a, b)
