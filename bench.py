@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 SEED = 20230211          # reference default seed (main/trainer.py:21)
 N_CONTEXT = 2            # extra context frames -> cond context 77 + 256*(1+N) tokens
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # PMC-derived bytes of this round's profile run
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # PMC-derived bytes of this round's profile run
 
 
 # BASELINE.json configs -> concrete runs (SURVEY.md section 8d "Configs -> concrete runs").  c1 is the metric's configuration and the
@@ -309,9 +309,9 @@ def gather_latents(dist, world):
             return 1
         flat = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)     # one buffer, one collective
         parts = flat.view((world,) + tuple(out.shape))
-        try:
+        if dist.get_backend() == "nccl":                 # the form is decided from the backend, never by catching a failed collective
             dist.all_gather_into_tensor(flat, out.contiguous())
-        except (RuntimeError, NotImplementedError):      # a backend without the tensor form
+        else:
             dist.all_gather(list(parts.unbind(0)), out.contiguous())
         sums = [float(p.double().abs().sum()) for p in parts]
         return len({round(s, 3) for s in sums if s == s and s != float("inf")})
@@ -573,7 +573,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--cfg-split", action="store_true", help="single-clip latency mode for 2 ranks: rank 0 runs the conditional, rank 1 the "
                     "unconditional forward of every step (camc2v_amd/parallel.py: CfgSplit; hipGraph per rank, strong scaling)")
     ap.add_argument("--shard-graph", action="store_true", help="with --frame-shard on RCCL: capture the sharded step, collectives included, "
-                    "into a hipGraph (the exchanges are issued on the compute stream); untested until a multi-GPU node is reachable")
+                    "into a hipGraph (the exchanges are issued on the compute stream); EXPERIMENTAL: has never run (no multi-GPU node was reachable)")
     ap.add_argument("--clips-only", action="store_true", help="profiling runs: no live kernel timing, no CPU baseline -- the trace then holds the clips' launches only")
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="c1", help="BASELINE.json configs: c1 (default, the metric's configuration: "
                     "CamContextI2V CFG 7.5), c0 (DynamiCrafter, CFG off), c3 (CamI2V baseline), c4 (32 frames, CFG 3.5)")
@@ -618,6 +618,18 @@ def main(argv=None, hooks=None):
                 dist.init_process_group("nccl", device_id=device)
             else:
                 dist.init_process_group(hooks.get("backend", "gloo"), rank=rank, world_size=world)
+
+    if dist is not None and on_gpu and not rehearsal:
+        # every rank on a device of its own, and RCCL sees all of them, before anything is timed
+        ids = [None] * world
+        props = torch.cuda.get_device_properties(device)
+        dist.all_gather_object(ids, (socket.gethostname(), torch.cuda.current_device(), str(getattr(props, "uuid", "")), getattr(props, "pci_bus_id", -1)))
+        if len(set(ids)) != world or dist.get_world_size() != world:
+            raise SystemExit(f"bench.py: {world} ranks but {len(set(ids))} distinct devices: {ids}")
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            raise SystemExit(f"bench.py: RCCL all_reduce saw {int(probe.item())} of {world} ranks")
 
     torch.set_grad_enabled(False)
     model = hooks.get("build_model", build_model)(device)

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libccv_hip.so")
-SOURCES = ["ccv_gemm.hip", "ccv_fused.hip", "ccv_attn.hip", "ccv_attn_fp8.hip", "ccv_norm.hip", "ccv_misc.hip", "ccv_pose.hip"]
+SOURCES = ["ccv_gemm.hip", "ccv_fused.hip", "ccv_attn.hip", "ccv_norm.hip", "ccv_misc.hip", "ccv_pose.hip"]
 HEADERS = [os.path.join(CSRC, "ccv_common.h"), os.path.join(os.path.dirname(HERE), "include", "ccv.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1287,7 +1287,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     }
     const uint32_t sched_addr = lds0 + SCHED;
     uint32_t e_next;                                    // entry of the step the next iteration issues (prefetched one step ahead)
-    asm volatile("ds_read_u16 %0, %1" : "=v"(e_next) : "v"(sched_addr + 2 * min(S - 1, n - 1)) : "memory");
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e_next) : "v"(sched_addr + 2 * min(S - 1, n - 1)) : "memory");   // (hipcc does not
+                                                        // track an inline-asm read: without the wait the first step could use the entry before it arrives)
     int i = 0;
     auto step = [&](auto stc) __attribute__((always_inline)) -> bool {
         constexpr int st = decltype(stc)::value;

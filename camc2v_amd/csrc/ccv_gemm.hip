@@ -1635,16 +1635,19 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
     const int lrow = lane >> 3, lchunk = lane & 7;
     const int wr = 8 * wave + lrow;                     // row of the strip (0..63) this lane fetches
     // weights through a buffer descriptor (as gemm_dma_kernel): the lane's offset inside a strip is fixed, the strip and the slab ride in
-    // the scalar offset.  Past the last strip the same number of pieces is issued with an out-of-range scalar offset (the hardware
-    // writes zeros into a stage nobody reads any more): every iteration then issues exactly PIECES DMA operations, so the counted
-    // waits below hold on every path.
+    // the scalar offset.  Past the last strip the same number of pieces is issued with an out-of-range PER-LANE offset (the probed form,
+    // tools/probes/buffer_lds_oob_probe.hip: the hardware writes zeros into a stage nobody reads any more; the scalar offset stays that of
+    // a real strip, so no signed overflow and no reliance on range-checking the scalar part): every iteration then issues exactly
+    // PIECES DMA operations, so the counted waits below hold on every path.
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.W), 0, DMA_RANGE, 0x00020000);
     const int w_off = (wr * K + ((lchunk ^ ((wr >> 1) & 7)) << 3)) * 2;
     auto issue = [&](int strip, int stage) {
-        const int soff = strip < nstrips ? strip * BN * K * 2 : DMA_NOWHERE;
+        const bool real = strip < nstrips;
+        const int soff = (real ? strip : 0) * BN * K * 2;
+        const int voff = real ? w_off : DMA_NOWHERE;
 #pragma unroll
         for (int q = 0; q < PIECES; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t*)(smem + stage * STAGE + (q * BN + 8 * wave) * 128), 16, w_off, soff + q * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lptr_t*)(smem + stage * STAGE + (q * BN + 8 * wave) * 128), 16, voff, soff + q * 128, 0, 0);
     };
     // Strip s lives in ring stage (s + 2) % 3: stages 0 and 1 first hold the ACTIVATION tile, staged by LDS-DMA in whole
     // 128-byte lines (8 rows x 128 B per piece, [slab][128 rows][128 B], same source-side swizzle as the weight image) and read
@@ -2123,7 +2126,8 @@ extern "C" int ccv_gemm(const CcvGemm* pp, void* stream) {
     CCV_REQUIRE(!p.gn_partial || (p.gn_rows > 0 && p.gn_slots > 0 && p.gn_slots == ccv_gemm_gn_slots(&p, p.gn_rows) &&
                                   (ccv_gemm_ws_bytes(&p) == 0 || p.split_k > 1)), CCV_EINVAL,
                 "ccv_gemm: gn_partial needs gn_rows and gn_slots = ccv_gemm_gn_slots() > 0 for this problem (got rows %d, slots %d)", p.gn_rows, p.gn_slots);
-    {   // the LDS-DMA kernels address both operands with 32-bit byte offsets from their base (buffer descriptors)
+    if (!p.a_f32 && !skinny_fits(p)) {   // the LDS-DMA kernels (family, ring, A-stationary) address both operands with 32-bit byte offsets from
+        // their base (buffer descriptors); the register-staged fp32-activation kernel and the skinny kernel keep 64-bit pointers
         long a_rows = p.M;
         if (p.gather == 1 && p.out_h > 0 && p.out_w > 0) a_rows = (long)(p.M / (p.out_h * p.out_w)) * p.src_h * p.src_w;
         else if (p.gather == 3) a_rows = (long)(p.taps - 1) * p.hw + p.M;

@@ -105,8 +105,6 @@ SIGNATURES = {
     "ccv_epipolar_mask_bits": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ccv_attn_group_order": (i32, [vp, i32, i32, i32, vp, vp]),
     "ccv_attn_group_order_merged": (i32, [vp, i32, i32, i32, i32, vp, vp]),
-    "ccv_attn_fp8_ws_bytes": (i64, [C.POINTER(CcvAttn)] + [C.POINTER(C.c_int64)] * 5),
-    "ccv_attn_sparse_fp8_fwd": (i32, [C.POINTER(CcvAttn), vp, i64, vp]),
     "ccv_attn_sparse_queue_item": (i64, [i32, i32, i32, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 

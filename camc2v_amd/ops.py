@@ -28,6 +28,7 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU = 0, 1, 2, 3
 
 # 0: V^T fragments through ds_read_b64_tr_b16; 1: V transposed while staging (fallback)
 ATTN_VARIANT = 0
+SPARSE_VARIANT = None   # tests / A-B aid: 6 = the per-wave sparse kernel, 4 / 5 = the workgroup-shared kernel with 8 / 4 waves, for every call that carries wave_bits
 
 
 def _stream():
@@ -42,6 +43,14 @@ def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise CcvError("camc2v_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _untag(t):
+    """An op is about to write into the caller-supplied tensor t: GroupNorm statistics riding on it (``_ccv_gn``, tag_stats) describe
+    the OLD contents -- the kernels write through raw pointers, so torch's ``_version`` never moves -- and are dropped here."""
+    if t is not None:
+        t.__dict__.pop("_ccv_gn", None)
+    return t
 
 
 def _rows(t):
@@ -106,6 +115,7 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
     conv = (out_h, out_w, src_h, src_w, stride, upsample[, no_lead_pad]); tconv = (frames, hw);
     seg_rows (GATHER_SEGMENTS): a = `taps` stacked operands, `seg_rows` rows apart; tap t multiplies rows [t*seg_rows, +M).
     """
+    _untag(out)
     ln = None
     if isinstance(a, LazyLN):       # try the LayerNorm prologue (decided below, once the problem is described); else the norm runs first
         ln = a
@@ -246,6 +256,7 @@ def ff_fused(x, gamma, beta, eps, w1, b1, w2p, b2, *, out=None, out_dtype=None):
     """out = x + Linear_2(value * gelu(gate)), [value | gate] = Linear_1(LayerNorm(x)) in ONE launch (include/ccv.h, ccv_ff_fused;
     reference lvdm/modules/attention.py:253,431-458).  x: the fp16 stream [M, C]; w1 / b1: GEGLU-interleaved (pack.interleave_geglu);
     w2p: pack.permute_k16_for_acc_operand(W2).  out: fp16 (default: a new tensor; may be x itself) or bf16."""
+    _untag(out)
     _dev(x, gamma, beta, w1, b1, w2p, b2, out)
     if x.dtype != F16 or x.dim() != 2 or x.stride(1) != 1:
         raise CcvError("ff_fused: x must be the fp16 stream [M, C] with a contiguous last dim")
@@ -325,6 +336,7 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
     """Fused attention, head dim 64.  *_str = (batch_outer, batch_inner, token) strides in elements;
     q/k/v are bf16 tensors whose data_ptr() is the element (batch 0, token 0, head 0, d 0).
     Returns bf16 [B*Lq, H*64] unless `out`/`o_str` are given."""
+    _untag(out)
     _dev(q, k, v, k2, v2, mask_bits, tile_flags, kreg, vreg, out)
     for t in (q, k, v, k2, v2, kreg, vreg):
         if t is not None and t.dtype != BF16:
@@ -379,11 +391,11 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
         p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
     if perm is not None:   # (frame tokens, frame width): rows and mask are in 4x8-patch order
         p.perm_hw, p.perm_w = perm
-    p.variant = ATTN_VARIANT if variant is None else variant
+    p.variant = (SPARSE_VARIANT if (SPARSE_VARIANT is not None and wave_bits is not None and mask_bits is not None and k2 is None) else ATTN_VARIANT) if variant is None else variant
     # measurement aid (bench.py): HIP events on the launch stream around the launches ccv_attn_fwd routes to the persistent
     # sparse kernel (same rule as csrc/ccv_attn.hip: block bitmap given and variant 3 or >= 1024 64-query groups)
     probe = SPARSE_PROBE if (wave_bits is not None and mask_bits is not None
-                             and (p.variant == 3 or ((Lq + 63) // 64) * H * B >= 1024)) else None
+                             and (p.variant >= 3 or ((Lq + 63) // 64) * H * B >= 1024)) else None
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -394,45 +406,6 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
     return out
 
 
-def attention_sparse_fp8(q, k, v, *, B, H, L, q_str, k_str, v_str, mask_bits, wave_bits, mask_nb=1, group_order=None, kreg=None, vreg=None,
-                         perm=None, out=None, scale=None):
-    """fp8 (e4m3) variant of the masked epipolar attention: same q / k / v (bf16, strided) and masks as ``attention``; quantises
-    into a workspace (per-(batch, head) scales), then runs the sparse kernel on fp8 MFMA.  Returns bf16 [B*L, H*64]."""
-    _dev(q, k, v, mask_bits, wave_bits, kreg, vreg, out)
-    for t in (q, k, v, kreg, vreg):
-        if t is not None and t.dtype != BF16:
-            raise CcvError("attention_sparse_fp8: q/k/v must be bf16")
-    if mask_bits.dtype != torch.int32 or not mask_bits.is_contiguous() or wave_bits.dtype != torch.int32 or not wave_bits.is_contiguous():
-        raise CcvError("attention_sparse_fp8: mask_bits / wave_bits must be contiguous int32")
-    if out is None:
-        out = torch.empty((B * L, H * 64), dtype=BF16, device=q.device)
-    p = CcvAttn()
-    p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(out)
-    p.q_bso, p.q_bsi, p.q_ls = q_str
-    p.k_bso, p.k_bsi, p.k_ls = k_str
-    p.v_bso, p.v_bsi, p.v_ls = v_str
-    p.o_bso, p.o_bsi, p.o_ls = L * H * 64, 0, H * 64
-    p.B, p.inner, p.H, p.Lq, p.Lk = B, 1, H, L, L
-    p.scale = scale if scale is not None else 1.0 / math.sqrt(64.0)
-    p.mask_bits, p.mask_words, p.mask_bs, p.mask_nb = _ptr(mask_bits), mask_bits.shape[-1], mask_bits.shape[-2] * mask_bits.shape[-1], mask_nb
-    p.wave_bits, p.wave_words, p.wave_bs = _ptr(wave_bits), wave_bits.shape[-1], wave_bits.shape[-2] * wave_bits.shape[-1]
-    ctr = _queue_counters(q.device)     # caller-owned work-queue counter (see ``attention``)
-    p.queue_counters = _ptr(ctr)
-    if group_order is not None:
-        p.group_order, p.order_bs = _ptr(group_order), group_order.shape[-1]
-    if kreg is not None:
-        p.kreg, p.vreg, p.nreg = _ptr(kreg), _ptr(vreg), kreg.shape[0]
-    if perm is not None:
-        p.perm_hw, p.perm_w = perm
-    nbytes = lib().ccv_attn_fp8_ws_bytes(C.byref(p), None, None, None, None, None)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-    check(lib().ccv_attn_sparse_fp8_fwd(C.byref(p), _ptr(ws), nbytes, _stream()), "ccv_attn_sparse_fp8_fwd")
-    return out
-
-
-# ---------------------------------------------------------------------------------------
-# norms
-# ---------------------------------------------------------------------------------------
 def groupnorm(x, gamma, beta, *, instances, eps, silu, stats=None):
     """x [rows, C] fp32|fp16|bf16 -> bf16; statistics per (instance, group of C/32 channels).  stats: what ``gemm(..., gn_rows=)``
     returned for the GEMM that produced x (the statistics pass is skipped), or None; a tensor tagged by ``tag_stats`` carries them."""
@@ -463,7 +436,9 @@ def groupnorm(x, gamma, beta, *, instances, eps, silu, stats=None):
 
 def tag_stats(out, stats):
     """Let ``out`` carry the GroupNorm statistics its producing GEMM emitted (``gemm(..., gn_rows=)`` -> (out, stats)): the next
-    ``groupnorm(out, ...)`` with matching instances skips its statistics pass.  The tag dies with any in-place write to ``out``."""
+    ``groupnorm(out, ...)`` with matching instances skips its statistics pass.  The tag dies with any in-place write to ``out``: torch
+    writes move ``_version``; this package's own kernels write through raw pointers, so every op that takes a caller-supplied output
+    (``gemm(out=)``, ``attention(out=)``, ``ff_fused(out=)``, ``layernorm(out2=)``) drops the tag explicitly (``_untag``)."""
     if stats is not None:
         out._ccv_gn = (stats[0], stats[1], out._version)
     return out
@@ -529,6 +504,7 @@ def groupnorm_apply_sums(x, gamma, beta, sums, *, instances, total_rows_per_inst
 
 def layernorm(x, gamma, beta, *, eps=1e-5, addend=None, out2=None):
     """x [rows, C] fp32|fp16 -> bf16 (and y + addend[r % addend_rows] when addend is given; `out2`: where that second output goes)."""
+    _untag(out2)
     _dev(x, gamma, beta, addend)
     xk = _kind(x, (F32, F16), "layernorm (the residual stream)")
     rows, Cc = _rows(x)
@@ -589,6 +565,7 @@ def concat_rows(a, b, with_bf16=False):
 
 def attention_small(q, k, v, *, B, inner, H, T, head_dim, q_str, k_str, v_str, out=None, o_str=None, scale=None):
     """Self-attention over T <= 16 tokens, any head width (multiple of 8, <= 256); strides as in ``attention``."""
+    _untag(out)
     _dev(q, k, v, out)
     for t in (q, k, v):
         if t.dtype != BF16:

@@ -2,13 +2,16 @@
 every clip are split evenly over the ranks of a ``torch.distributed`` group (RCCL over xGMI on a node: backend "nccl"; the CPU-side
 tests use gloo); every rank runs the UNet on its frames and the layers that mix frames exchange what they need:
 
-  * ``TemporalConvBlock``: per convolution ONE all_gather carrying the rank's partial GroupNorm sums [b, 32 groups, 2] AND its two
-    edge frames (un-normalised; every rank normalises the halo frames it receives with the same clip-wide statistics);
+  * ``TemporalConvBlock``: per convolution ONE collective -- an uneven all_to_all in which every rank sends its partial GroupNorm
+    sums [b, 32 groups, 2] to everybody and its first / last (un-normalised) frame ONLY to the rank that holds the neighbouring frames
+    (round 4; rounds 2-3 all-gathered every rank's two edge frames: world x the bytes a rank uses); every rank normalises the two
+    halo frames it receives with the same clip-wide statistics;
   * ``TemporalTransformer`` GroupNorm over (t, h, w): one all_reduce of the sums;
   * temporal self-attention (per pixel over t) and the epipolar attention (over all t*h*w tokens): the K | V of a camera block's two
     attentions travel in one all_gather, the second temporal attention's in another;
   * the UNet output: one all_gather of the predicted noise, so that every rank runs the (tiny) DDIM update on whole clips.
-All gathers are ``all_gather_into_tensor`` into one [world, ...] buffer, issued on the compute stream.
+All gathers are ``all_gather_into_tensor`` into one [world, ...] buffer, issued on the compute stream; which form of a collective a
+backend gets is decided ONCE from its name (never by catching a failed collective: ranks that disagree would hang).
 
 This is 140 collectives per forward (22 x 4 temporal convolutions + 17 norms + 16 + 17 + 1 K|V gathers + 1; round 2: ~250): the
 frame-mixing layers are sequentially dependent, so it stays a latency mode for ONE clip on several GPUs -- independent clips
@@ -55,21 +58,26 @@ def broadcast_from_first(t, group=None):
     return t
 
 
-def _gather_into(x, world, group, state):
+def _tensor_collectives(group):
+    """True when the backend has the single-buffer device collectives (all_gather_into_tensor, all_to_all_single on device tensors):
+    RCCL ("nccl").  Decided from the backend's name, once per group -- NOT by catching a failing collective: if a collective failed on
+    some ranks only (an asynchronous RCCL error, a timeout), the ranks would diverge onto different collectives and hang, and the
+    real error would be swallowed."""
+    return dist.get_backend(group) == "nccl"
+
+
+def _gather_into(x, world, group, state=None):
     """x (same shape on every rank) -> [world, *x.shape]: ONE all_gather_into_tensor into one buffer (no per-rank list, no stack
-    copy).  Backends without the tensor form (seen: gloo on device tensors in some builds) fall back to the list form, once."""
+    copy) on RCCL; the list form on backends without the tensor form (gloo: the tests)."""
     x = x.contiguous()
     if x.dim() == 0:
         x = x.reshape(1)
     flat = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)   # the ranks' tensors back to back
     out = flat.view((world,) + tuple(x.shape))
-    if state.get("into_tensor", True):
-        try:
-            dist.all_gather_into_tensor(flat, x, group=group)
-            return out
-        except (RuntimeError, NotImplementedError):
-            state["into_tensor"] = False
-    dist.all_gather(list(out.unbind(0)), x, group=group)
+    if _tensor_collectives(group):
+        dist.all_gather_into_tensor(flat, x, group=group)
+    else:
+        dist.all_gather(list(out.unbind(0)), x, group=group)
     return out
 
 
@@ -92,6 +100,47 @@ class FrameShard:
         """x (same shape on every rank) -> [world, *x.shape] (index r = rank r's tensor)."""
         self.collectives += 1
         return _gather_into(x, self.world, self.group, self._state)
+
+    def neighbour_exchange(self, first, last, shared):
+        """ONE collective: `shared` (a small tensor, e.g. partial GroupNorm sums) goes to every rank, `first` to rank - 1 and `last` to
+        rank + 1 only.  Returns (every rank's `shared` [world, *shape], rank - 1's `last` or None, rank + 1's `first` or None).
+        An all_to_all with per-peer sizes: under RCCL a group of point-to-point sends / receives over the xGMI links to the two
+        neighbours -- a rank receives 2 frames instead of the 2 x world of an all-gather."""
+        self.collectives += 1
+        r, w = self.rank, self.world
+        sh = shared.contiguous().view(torch.uint8).reshape(-1)
+        sh = torch.cat([sh, sh.new_zeros((-sh.numel()) % 16)])                 # keep the frames 16-byte aligned behind it
+        fb, lb = first.contiguous().view(torch.uint8).reshape(-1), last.contiguous().view(torch.uint8).reshape(-1)
+        ns, nf = sh.numel(), fb.numel()
+        send, in_sizes, out_sizes = [], [], []
+        for d in range(w):
+            parts = [sh]
+            if d == r - 1:
+                parts.append(fb)          # my first frame is the frame after rank - 1's last one
+            if d == r + 1:
+                parts.append(lb)
+            send.extend(parts)
+            in_sizes.append(sum(p.numel() for p in parts))
+            out_sizes.append(ns + (nf if d in (r - 1, r + 1) else 0))
+        inp = torch.cat(send)
+        out = torch.empty(sum(out_sizes), dtype=torch.uint8, device=inp.device)
+        if _tensor_collectives(self.group):
+            dist.all_to_all_single(out, inp, out_sizes, in_sizes, group=self.group)
+        else:
+            # gloo (the tests): all_to_all on host tensors; the current stream is drained by the copy
+            out_h = torch.empty(out.shape, dtype=torch.uint8)
+            dist.all_to_all_single(out_h, inp.cpu(), out_sizes, in_sizes, group=self.group)
+            out.copy_(out_h)
+        got_shared, prev, nxt, off = [], None, None, 0
+        for s_ in range(w):
+            got_shared.append(out[off:off + shared.numel() * shared.element_size()])
+            if s_ == r - 1:
+                prev = out[off + ns:off + ns + nf].view(last.dtype).reshape(last.shape)
+            if s_ == r + 1:
+                nxt = out[off + ns:off + ns + nf].view(first.dtype).reshape(first.shape)
+            off += out_sizes[s_]
+        all_shared = torch.stack(got_shared, 0).view(shared.dtype).reshape((w,) + tuple(shared.shape))
+        return all_shared, prev, nxt
 
     def all_gather_packed(self, tensors):
         """Several tensors of any dtypes in ONE collective: they travel as one byte buffer.  Returns, per input tensor, the gathered
@@ -183,17 +232,21 @@ class FrameCtx:
         behind every clip's local frames (zeros at the clip's ends: the convolution's padding)."""
         C = rows.shape[-1]
         z = rows.reshape(b, self.t_loc, hw, C)
-        prev, nxt = self.halo_frames(self.shard.all_gather(torch.stack([z[:, 0], z[:, -1]], 0)))          # [2, b, hw, C] per rank
+        _, prev, nxt = self.shard.neighbour_exchange(z[:, 0], z[:, -1], rows.new_zeros(4))
+        prev = torch.zeros_like(z[:, 0]) if prev is None else prev
+        nxt = torch.zeros_like(z[:, 0]) if nxt is None else nxt
         return torch.cat([prev[:, None], z, nxt[:, None]], 1).reshape(b * (self.t_loc + 2) * hw, C)
 
     def edges_and_sums(self, rows, sums, b, hw):
-        """ONE collective for a temporal convolution's GroupNorm + halo: every rank's edge frames of the UN-normalised rows together
-        with its partial GroupNorm sums [b, 64].  Returns (previous rank's last frame, next rank's first frame, summed statistics,
-        is_first, is_last): the caller normalises its own rows and the two halo frames with the same clip-wide statistics."""
+        """ONE collective for a temporal convolution's GroupNorm + halo (FrameShard.neighbour_exchange): the partial GroupNorm sums
+        [b, 64] of every rank, and of the UN-normalised rows only the two frames this rank needs -- rank - 1's last and rank + 1's first.
+        Returns (previous frame, next frame, summed statistics, is_first, is_last): the caller normalises its own rows and the two halo
+        frames with the same clip-wide statistics (zeros stand in at the clip's ends and are overwritten by the caller)."""
         C = rows.shape[-1]
         z = rows.reshape(b, self.t_loc, hw, C)
-        edges, all_sums = self.shard.all_gather_packed([torch.stack([z[:, 0], z[:, -1]], 0), sums])
-        prev, nxt = self.halo_frames(edges)
+        all_sums, prev, nxt = self.shard.neighbour_exchange(z[:, 0], z[:, -1], sums)
+        prev = torch.zeros_like(z[:, 0]) if prev is None else prev
+        nxt = torch.zeros_like(z[:, 0]) if nxt is None else nxt
         return prev, nxt, all_sums.sum(0), self.shard.rank == 0, self.shard.rank == self.shard.world - 1
 
     def inner(self, rows_ext, b, hw):

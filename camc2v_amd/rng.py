@@ -30,14 +30,18 @@ class seeded:
     def __init__(self, seed, device):
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        # a host-side draw inside the block stays per-sample reproducible too: a CPU generator seeded from the same value
+        self.host = self.gen if torch.device(device).type == "cpu" else torch.Generator(device="cpu")
+        if self.host is not self.gen:
+            self.host.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
 
     def __enter__(self):
-        self.prev = generator()
-        _TLS.gen = self.gen
+        self.prev = (generator(), getattr(_TLS, "host", None))
+        _TLS.gen, _TLS.host = self.gen, self.host
         return self.gen
 
     def __exit__(self, *exc):
-        _TLS.gen = self.prev
+        _TLS.gen, _TLS.host = self.prev
         return False
 
 
@@ -46,7 +50,11 @@ def _gen_for(device):
     if g is None:
         return None
     kind = torch.device(device).type if device is not None else "cpu"
-    return g if kind == g.device.type else None     # a host-side draw while a device generator is installed: default generator
+    if kind == g.device.type:
+        return g
+    if kind == "cpu":
+        return getattr(_TLS, "host", None)          # the block's host generator (same seed): still one stream of draws per sample
+    raise RuntimeError(f"rng: a draw on {kind!r} inside a seeded block whose generator lives on {g.device.type!r}")
 
 
 def randn(*size, **kw):

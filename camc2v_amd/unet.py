@@ -33,9 +33,6 @@ from .lib import CcvError
 Geom = namedtuple("Geom", "b t h w")
 # A/B aid: CCV_FUSE_CAM=0 runs the three stream updates of a camera-conditioned temporal block as three GEMMs
 FUSE_CAMERA_PROJECTIONS = __import__("os").environ.get("CCV_FUSE_CAM", "1") != "0"
-# CCV_ATTN_FP8=1: the masked epipolar attention of feature maps with >= FP8_EPIPOLAR_MIN_TOKENS tokens runs the e4m3 kernel
-FP8_EPIPOLAR = __import__("os").environ.get("CCV_ATTN_FP8", "0") == "1"
-FP8_EPIPOLAR_MIN_TOKENS = 2048
 # A/B aid: CCV_FUSE_FF=0 runs every feed-forward as LayerNorm + two GEMMs (the one-launch form exists for C = 320: csrc/ccv_fused.hip)
 FUSE_FF = __import__("os").environ.get("CCV_FUSE_FF", "1") != "0"
 TEXT_LEN = 77  # CrossAttention.text_context_len (reference attention.py:49)
@@ -403,11 +400,6 @@ class Epipolar(nn.Module, _Prepared):
                 kw.update(out=out, o_str=(L * C, 0, C))
             return ops.attention(qkv, kv, kv[:, C:], B=g.b, inner=1, H=H, Lq=L, Lk=La, q_str=s, k_str=(La * 2 * C, 0, 2 * C),
                                  v_str=(La * 2 * C, 0, 2 * C), kreg=pk.get("kreg"), vreg=pk.get("vreg"), scale=self.epipolar_attn.scale, **kw)
-        if FP8_EPIPOLAR and kw and kw.get("wave_bits") is not None and L >= FP8_EPIPOLAR_MIN_TOKENS:
-            # BASELINE.json configs[4]: e4m3 q / K / V / P with fp32 softmax (off by default: measured in DESIGN.md section 4)
-            return ops.attention_sparse_fp8(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, H=H, L=L, q_str=s, k_str=s, v_str=s, mask_bits=kw["mask_bits"],
-                                            wave_bits=kw["wave_bits"], mask_nb=kw["mask_nb"], group_order=kw.get("group_order"), kreg=pk.get("kreg"),
-                                            vreg=pk.get("vreg"), perm=kw.get("perm"), out=out, scale=self.epipolar_attn.scale)
         if out is not None:
             kw.update(out=out, o_str=(L * C, 0, C))
         return ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=g.b, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s,

@@ -380,17 +380,6 @@ int ccv_epipolar_mask_bits(const float* F, uint32_t* bits, uint8_t* flags, uint3
 int ccv_epipolar_mask_bits_rect(const float* F, uint32_t* bits, uint8_t* flags, uint32_t* wave_bits,
                                 int32_t B, int32_t Tq, int32_t Tk, int32_t H, int32_t W, int32_t downsample, int32_t patch_order,
                                 void* stream);
-/* ------------------------------------------------------------------------------------
- * fp8 (OCP e4m3) variant of the masked epipolar attention (BASELINE.json configs[4]; reference call site
- * F.scaled_dot_product_attention, model/modules/epipolar.py:99).  Same arguments as the masked ccv_attn_fwd call (bf16 q / k /
- * v with strides, mask_bits, wave_bits, group_order, kreg / vreg, perm_hw / perm_w, bf16 output; Lq == Lk, inner == 1, one
- * context).  The call first quantises into the caller's workspace -- per-(batch, head) scales from the amax of q, k (+ register
- * keys) and v, q as e4m3 rows, K as block-contiguous e4m3 [(b h)][block][32][64], V as transposed e4m3 blocks
- * [(b h)][block][64][32], token permutation applied -- then runs the sparse kernel on v_mfma_f32_32x32x16_fp8_fp8 with the
- * softmax in fp32 and P in e4m3.  Half the K/V bytes and 5 instead of 9 DMA operations per visited 32-key block.
- * ccv_attn_fp8_ws_bytes: workspace size (the *_off outputs are optional sub-buffer offsets, for tests). */
-int64_t ccv_attn_fp8_ws_bytes(const CcvAttn* p, int64_t* q8_off, int64_t* k8_off, int64_t* v8_off, int64_t* scales_off, int64_t* amax_off);
-int ccv_attn_sparse_fp8_fwd(const CcvAttn* p, void* ws, int64_t ws_bytes, void* stream);
 
 /* Host-side view of the sparse attention kernel's per-XCD work queues (no device work; tests): the kernel gives each of the 8
  * XCDs a longest-first queue of (batch-head slice, rank) items -- the slices s with s % 8 == xq in full plus an equal share of

@@ -1,0 +1,103 @@
+"""The other BASELINE.json configurations at FULL width (the round-3 review's parity gaps):
+
+  * configs[3], CamI2V-256 baseline (`baseline.cami2v.CamI2V`: Pluecker features + epipolar attention, per-frame context 77 + 16 x 16 on BOTH
+    CFG passes): one CFG step's UNet work of the full 1.5 B-parameter network against the fp32 oracle on the host, rel-L2 <= 2.5e-2
+    per half (replaces the 1e-1 bound of the ill-conditioned small network as the statement about this configuration);
+  * configs[4], a 32-frame clip at full width (L = 32768 epipolar tokens at 32x32 latents, context 77 + 16 x 32, CFG pair): the oracle's
+    dense fp32 attention over 32768 x 32768 scores does not fit a test, so the full-width statement is a size-independent property --
+    the forward through the workgroup-shared sparse attention kernel equals, BIT FOR BIT, the forward through the per-wave kernel
+    (two independent schedules of the same arithmetic), finite, of the right shape; parity against the oracle at 32 frames is held at
+    medium width in tests/test_unet_gpu.py::test_config4_32_frames_cfg_3p5_medium.
+"""
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REL_L2, MAX_REL = 2.5e-2, 8e-2
+
+
+class _workload:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        import bench
+        self.prev = (bench.WORKLOAD, bench.WORKLOAD_KEY)
+        bench.WORKLOAD, bench.WORKLOAD_KEY = bench.WORKLOADS[self.key], self.key
+        return bench
+
+    def __exit__(self, *exc):
+        import bench
+        bench.WORKLOAD, bench.WORKLOAD_KEY = self.prev
+
+
+def test_full_size_cami2v_cfg_step_vs_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import configs
+    from oracle import geometry_oracle, unet_oracle
+    dev = torch.device("cuda:0")
+    torch.set_grad_enabled(False)
+    with _workload("c3") as bench:
+        model = bench.build_model(dev)
+        assert type(model).__name__ == "CamI2V"
+        inputs = bench.synthetic_inputs(model, dev)
+        cond, uncond, fs, x_T, _ = inputs
+        assert cond["c_crossattn"][0].shape[1] == 333 and uncond["c_crossattn"][0].shape[1] == 333
+        got = [e.float().cpu() for e in bench.cfg_step(model, dev, inputs, t_value=439)]
+    sd = {k: v.detach().float().cpu() for k, v in model.model.diffusion_model.state_dict().items()}
+    cam = cond["camera_condition"]
+    F = cam["fundamental"].float().cpu()
+    masks = {d: geometry_oracle.epipolar_mask(F, 256 // d, 256 // d, d) for d in (8, 16, 32, 64)}
+    cam_cpu = dict(pluker_embedding_features=[f.float().cpu() for f in cam["pluker_embedding_features"]], sample_locs_dict=masks,
+                   add_type=cam["add_type"])
+    xin = torch.cat([x_T, cond["c_concat"][0]], 1).float().cpu()
+    t = torch.full((1,), 439, dtype=torch.long)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    t0 = time.perf_counter()
+    for g, ctx, half in zip(got, (cond["c_crossattn"][0], uncond["c_crossattn"][0]), ("conditional", "unconditional")):
+        ref = unet_oracle.unet_forward(sd, dict(configs.UNET_256), xin, t, ctx.float().cpu(), fs.cpu(), cam_cpu, origin_h=256)
+        l2 = ((g - ref).norm() / ref.norm()).item()
+        mx = ((g - ref).abs().max() / ref.abs().max()).item()
+        print(f"[parity] full-size CamI2V (configs[3]) CFG step, {half} half (ctx 333, per-frame) vs fp32 oracle: rel_l2={l2:.3e} max_rel={mx:.3e}")
+        assert torch.isfinite(g).all() and l2 <= REL_L2 and mx <= MAX_REL, (half, l2, mx)
+    print(f"[parity] oracle: two forwards in {time.perf_counter() - t0:.1f} s")
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_full_size_32_frame_forward_shared_kernel_equals_per_wave_kernel():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from camc2v_amd import ops
+    dev = torch.device("cuda:0")
+    torch.set_grad_enabled(False)
+    with _workload("c4") as bench:
+        model = bench.build_model(dev)
+        inputs = bench.synthetic_inputs(model, dev)
+        assert inputs[3].shape == (1, 4, 32, 32, 32) and inputs[0]["c_crossattn"][0].shape[1] == 77 + 16 * 32
+        keep = ops.SPARSE_VARIANT
+        try:
+            outs = {}
+            for variant in (0, 6):          # 0: the default routing (workgroup-shared sparse kernel); 6: the per-wave sparse kernel
+                ops.SPARSE_VARIANT = None if variant == 0 else variant
+                outs[variant] = [e.float() for e in bench.cfg_step(model, dev, inputs, t_value=439)]
+                torch.cuda.synchronize()
+        finally:
+            ops.SPARSE_VARIANT = keep
+    for a, b, half in zip(outs[0], outs[6], ("conditional", "unconditional")):
+        assert a.shape == (1, 4, 32, 32, 32) and torch.isfinite(a).all()
+        assert torch.equal(a, b), f"{half}: shared-K/V kernel and per-wave kernel disagree by {(a - b).abs().max().item():.3e}"
+        print(f"[parity] full-size 32-frame CFG pair, {half} half: |eps| max {a.abs().max().item():.3f}, rms {a.pow(2).mean().sqrt().item():.3f}; "
+              "shared-K/V kernel == per-wave kernel bit for bit")
+    assert not torch.equal(outs[0][0], outs[0][1])
+    del model
+    torch.cuda.empty_cache()

@@ -34,12 +34,26 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.bfloat16):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
 
 
-def assert_close(got, ref, tol, what=""):
+L2_REPORT = os.environ.get("CCV_TEST_L2_REPORT")     # a file: every comparison's (what, tol, rel-L2) is appended (bound-setting aid)
+
+
+def assert_close(got, ref, tol, what="", l2=None):
+    """Two bounds.  (1) max |err| <= tol * max |ref| (range-relative: catches a wrong element anywhere).  (2) relative L2
+    ||got - ref|| / ||ref|| <= l2, default 0.4 * tol -- 4e-3 for the bf16-output cases (tol 1e-2), 8e-4 for the fp32-output cases on
+    bf16-representable inputs (tol 2e-3): the range metric alone would pass a systematic ~1 % error on the many small elements
+    (round-3 review); a rounding-level error has rel-L2 ~ 2^-9 / sqrt(3) ~ 1.1e-3 for one bf16 rounding of the output."""
     got, ref = got.float().cpu(), ref.float().cpu()
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert math.isfinite(err), f"{what}: non-finite output"
     assert err <= tol * max(scale, 1e-6), f"{what}: max abs err {err:.4e} vs absmax {scale:.4e} (tol {tol})"
+    rl2 = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+    if L2_REPORT:
+        with open(L2_REPORT, "a") as f:
+            f.write(f"{what}\t{tol}\t{rl2:.3e}\n")
+        return
+    bound = 0.4 * tol if l2 is None else l2
+    assert rl2 <= bound, f"{what}: rel-L2 {rl2:.3e} > {bound:.1e} (max-norm bound {tol} passed)"
 
 
 # ------------------------------------------------------------------------------------------
@@ -867,80 +881,6 @@ def test_gemm_a_stationary_short_k(ops, kind, monkeypatch):
     assert ops.LAST_GEMM_PLAN[0] != -4
     ops.gemm(rnd(M, 640, seed=414), rnd(320, 640, seed=415))
     assert ops.LAST_GEMM_PLAN[0] != -4
-
-
-def _epipolar_setup(hl, H, B=2, seed=3):
-    """Benchmark-trajectory masks for an hl x hl feature map (16 frames) + q/k/v/register tokens for H heads."""
-    from camc2v_amd import camera
-    from camc2v_amd import ops as o
-    T, px = 16, 8 * 32
-    d = px // hl
-    K = torch.tensor([[px / 2, 0, px / 2], [0, px / 2, px / 2], [0, 0, 1.0]], device=dev()).repeat(1, T, 1, 1)
-    w2c = camera.synthetic_trajectory(1, T, dev())
-    F = camera.pairwise_fundamental(K, camera.relative_c2w(w2c, torch.zeros(1, dtype=torch.long, device=dev())),
-                                    generator=torch.Generator(device=dev()).manual_seed(seed))
-    po = o.patch_order_ok(hl, hl)
-    mp = o.epipolar_mask_bits(F, T, hl, hl, d, patch_order=po)
-    L = T * hl * hl
-    return mp, L, ((hl * hl, hl) if po else None)
-
-
-@pytest.mark.parametrize("hl,H", [(16, 10), (8, 4)])
-def test_attention_sparse_fp8(ops, hl, H):
-    """e4m3 variant of the masked epipolar attention (BASELINE.json configs[4]).  (1) q / k / v drawn from values that e4m3
-    represents exactly after the per-head scaling: the only rounding left is P in e4m3 (3 mantissa bits) and the bf16 output,
-    so the result must sit within 3e-2 of fp32 attention (measured 2.1e-2) -- any layout / permutation / mask mistake would be O(1).  (2) Gaussian q / k / v: the
-    error against the bf16 sparse kernel is the quantisation noise of e4m3 operands; stated bound rel-L2 6e-2."""
-    mp, L, perm = _epipolar_setup(hl, H)
-    B, C = 2, H * 64
-    g = torch.Generator().manual_seed(21)
-    s = (L * 3 * C, 0, 3 * C)
-    common = dict(q_str=s, k_str=s, v_str=s, mask_bits=mp[0], wave_bits=mp.wave_bits, mask_nb=1, group_order=mp.group_order, perm=perm)
-
-    def dense_ref(qkv, kreg, vreg):       # fp32 attention with the bool mask rebuilt from the packed bits (raster token order)
-        bits = mp[0][0].cpu().numpy().view(np.uint32)
-        m = np.unpackbits(bits.view(np.uint8), axis=-1, bitorder="little")[:, :L].astype(bool)
-        if perm is not None:              # rows and bit columns are in patch order: bring both back to raster
-            hw, w = perm
-            idx = np.arange(L)
-            f, rem = idx // hw, idx % hw
-            patch, within = rem >> 5, rem & 31
-            ppr = w >> 3
-            raster = f * hw + ((patch // ppr) * 4 + (within >> 3)) * w + (patch % ppr) * 8 + (within & 7)
-            mr = np.zeros_like(m)
-            mr[np.ix_(raster, raster)] = m
-            m = mr
-        mask = torch.from_numpy(m)
-        x = qkv.float().cpu().reshape(B, L, 3, H, 64)
-        q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
-        kr = kreg.float().cpu().reshape(-1, H, 64).permute(1, 0, 2)[None].expand(B, -1, -1, -1)
-        vr = vreg.float().cpu().reshape(-1, H, 64).permute(1, 0, 2)[None].expand(B, -1, -1, -1)
-        k, v = torch.cat([kr, k], 2), torch.cat([vr, v], 2)
-        full = torch.cat([torch.ones(L, kr.shape[2], dtype=torch.bool), mask], 1)
-        sim = (q @ k.transpose(-1, -2)) * 0.125
-        sim = sim.masked_fill(~full[None, None], float("-inf"))
-        return (sim.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * L, C)
-
-    # (1) exactly representable operands: values in {0, +-0.25, +-0.5, +-1} x amax, amax = 1 in every head
-    levels = torch.tensor([-1.0, -0.5, -0.25, 0.0, 0.25, 0.5, 1.0])
-    qkv = levels[torch.randint(0, 7, (B * L, 3 * C), generator=g)]
-    qkv[0, :] = 1.0                       # every (batch, head) slice of q, k, v sees |x| = 1
-    qkv[L, :] = 1.0
-    qkv = qkv.to(torch.bfloat16).to(dev())
-    reg = levels[torch.randint(0, 7, (4, C), generator=g)].to(torch.bfloat16).to(dev())
-    out = ops.attention_sparse_fp8(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, H=H, L=L, kreg=reg, vreg=reg, **common)
-    ref = dense_ref(qkv, reg, reg)
-    assert_close(out, ref, 3e-2, f"fp8 attention, exactly representable operands, {hl}x{hl}")
-    # (2) Gaussian operands against the bf16 sparse kernel
-    qkv = torch.randn(B * L, 3 * C, generator=g).to(torch.bfloat16).to(dev())
-    reg = torch.randn(4, C, generator=g).to(torch.bfloat16).to(dev())
-    out8 = ops.attention_sparse_fp8(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, H=H, L=L, kreg=reg, vreg=reg, **common)
-    out16 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B=B, inner=1, H=H, Lq=L, Lk=L, q_str=s, k_str=s, v_str=s, mask_bits=mp[0],
-                          tile_flags=mp[1], mask_nb=1, wave_bits=mp.wave_bits, group_order=mp.group_order, perm=perm, kreg=reg, vreg=reg, variant=3)
-    l2 = ((out8.float() - out16.float()).norm() / out16.float().norm()).item()
-    print(f"[parity] fp8 vs bf16 sparse attention, Gaussian operands, {hl}x{hl} latents H={H}: rel_l2={l2:.3e}")
-    assert torch.isfinite(out8).all() and l2 < 6e-2
-    assert_close(out16, dense_ref(qkv, reg, reg), 1e-2, "bf16 sparse kernel vs fp32 (sanity of the reference construction)")
 
 
 # ------------------------------------------------------------------------------------------

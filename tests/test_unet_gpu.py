@@ -474,47 +474,15 @@ def test_fused_camera_projections_equal_three_gemms(small, monkeypatch):
     _check(y_fused, y_three, "fused vs separate", 5e-2, 8e-2)      # this fixture amplifies any rounding difference (see header)
 
 
-def test_fp8_epipolar_attention_in_model(golden_dir, monkeypatch):
-    """BASELINE.json configs[4]: the UNet with the e4m3 epipolar attention (CCV_ATTN_FP8) on the medium fixture (16x16 latents,
-    L = 4096 tokens) against the reference's fp32 output: stated tolerance rel-L2 <= 3e-2 (bf16 path: 2.1e-2)."""
+def test_config4_32_frames_cfg_3p5_medium(golden_dir):
+    """BASELINE.json configs[4] -- a 32-frame clip at CFG 3.5 -- at the medium width (model_channels 128, 16x16 latents: epipolar
+    attention over L = 32 * 256 = 8192 tokens through the workgroup-shared sparse kernel, context rule 77 + 16 * 32 on both CFG
+    passes): a 2-step DDIM trajectory (guidance_rescale 0.7, eta 0) through `model.camcontexti2v.CamContextI2V` + DDIMSampler against
+    the fp32 oracle UNet + oracle sampler on the host.  Stated tolerance: rel-L2 of the final latents <= 6e-2 (guidance amplifies
+    the per-forward error by ~(1 + 2 * 3.5 * rescale)).  The e4m3 (fp8 MFMA) attention variant that configs[4] names was built in
+    round 2, measured slower than the bf16 kernel in rounds 2-4 and retired in round 4 (profiles/r04_fp8_retired.txt)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    from camc2v_amd import camera, unet as unet_mod
-    from oracle import unet_oracle as uo
-    from oracle.golden_inputs import MEDIUM_CFG, SEED, medium_inputs
-    from utils.utils import instantiate_from_config
-    fx = np.load(os.path.join(golden_dir, "unet_medium.npz"))
-    man = json.load(open(os.path.join(golden_dir, "unet_medium_manifest.json")))
-    unet = instantiate_from_config({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": MEDIUM_CFG})
-    unet.enable_camera_conditioning(dict(origin_h=128, origin_w=128, is_3d_full_attn=False, num_register_tokens=4,
-                                         attention_resolution=[8, 4, 2, 1], compression_factor=1))
-    unet.epipolar_origin_h = 128
-    unet.load_state_dict(uo.seeded_state_dict(man, SEED), strict=True)
-    unet = unet.cuda().eval()
-    inp = medium_inputs()
-    packed = camera.epipolar_masks_packed(torch.from_numpy(fx["F128"]).cuda(), 16, 128, 128)
-    cam = dict(pluker_embedding_features=[f.cuda() for f in inp["feats"]], sample_locs_dict=None, sample_locs_packed=packed,
-               add_type="add_to_main_branch")
-    args = dict(context=inp["ctx_rep"].cuda(), fs=inp["fs"].cuda(), camera_condition=cam)
-    y16 = unet(inp["x"].cuda(), inp["t"].cuda(), **args)
-    monkeypatch.setattr(unet_mod, "FP8_EPIPOLAR", True)
-    y8 = unet(inp["x"].cuda(), inp["t"].cuda(), **args)
-    assert not torch.equal(y8, y16)                  # the e4m3 kernel did run (L = 4096 >= FP8_EPIPOLAR_MIN_TOKENS)
-    _check(y16, fx["y_cam_rep"], "medium, bf16 epipolar attention vs reference fixture", 2.5e-2, 5e-2)
-    _check(y8, fx["y_cam_rep"], "medium, e4m3 epipolar attention vs reference fixture", 3e-2, 6e-2)
-    _check(y8, y16, "e4m3 vs bf16 epipolar attention in the model", 2.5e-2, 6e-2)
-
-
-def test_config4_as_written_32_frames_cfg_3p5_fp8_medium(golden_dir, monkeypatch):
-    """BASELINE.json configs[4] as written -- a 32-frame clip at CFG 3.5 with the e4m3 (fp8 MFMA) epipolar attention, all three
-    together -- at the medium width (model_channels 128, 16x16 latents: epipolar attention over L = 32 * 256 = 8192 tokens, context
-    rule 77 + 16 * 32 on both CFG passes): a 2-step DDIM trajectory (guidance_rescale 0.7, eta 0) through
-    `model.camcontexti2v.CamContextI2V` + DDIMSampler against the fp32 oracle UNet + oracle sampler on the host.  Stated tolerance:
-    rel-L2 of the final latents <= 6e-2 (bf16 attention on the same case: printed beside it; guidance amplifies the per-forward
-    error by ~(1 + 2 * 3.5 * rescale))."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    from camc2v_amd import unet as unet_mod
     from oracle import ddim_oracle, unet_oracle
     from oracle.golden_inputs import MEDIUM_CFG, SEED, small_inputs
     from utils.utils import instantiate_from_config
@@ -558,8 +526,4 @@ def test_config4_as_written_32_frames_cfg_3p5_fp8_medium(golden_dir, monkeypatch
         return out
 
     x16 = sample()
-    monkeypatch.setattr(unet_mod, "FP8_EPIPOLAR", True)
-    x8 = sample()
-    assert not torch.equal(x8, x16)                  # the e4m3 kernel did run (L = 8192 >= FP8_EPIPOLAR_MIN_TOKENS)
-    _check(x16, ref.numpy(), "configs[4] medium, 32 frames, CFG 3.5, bf16 epipolar attention: 2-step trajectory vs oracle", 6e-2, 1.5e-1)
-    _check(x8, ref.numpy(), "configs[4] medium, 32 frames, CFG 3.5, e4m3 epipolar attention: 2-step trajectory vs oracle", 6e-2, 1.5e-1)
+    _check(x16, ref.numpy(), "configs[4] medium, 32 frames, CFG 3.5: 2-step trajectory vs oracle", 6e-2, 1.5e-1)

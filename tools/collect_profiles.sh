@@ -4,7 +4,7 @@
 #   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r03'
 # Summaries land in gpurun_out/<tag>_prof/ ; copy what is to be judged into profiles/.
 set -eo pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/${tag}_prof
 mkdir -p "$out"
 export TMPDIR=/tmp

@@ -4,7 +4,7 @@
 Needs the DIAGNOSTIC build of the library (never the shipped one): ccv_gemm.hip compiled with -DCCV_FAMILY_STAMPS and linked with the
 other objects, handed over as CCV_HIP_LIB:
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DCCV_FAMILY_STAMPS -c camc2v_amd/csrc/ccv_gemm.hip -o /tmp/gemm_stamps.o
-    hipcc --offload-arch=gfx950 -shared -fPIC -o camc2v_amd/libccv_hip_stamps.so /tmp/gemm_stamps.o camc2v_amd/build/ccv_{attn,attn_fp8,norm,misc,pose}.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o camc2v_amd/libccv_hip_stamps.so /tmp/gemm_stamps.o camc2v_amd/build/ccv_{attn,fused,norm,misc,pose}.o
     CCV_HIP_LIB=$PWD/camc2v_amd/libccv_hip_stamps.so CCV_GEMM_TUNE=1 python tools/family_stamps.py
 Lane 0 of every wave stamps, per 64-deep slab: (0) top, (1) next slab's DMA issued, (2) fragment reads done + all MFMAs issued,
 (3) s_waitcnt vmcnt(0) passed, (4) barrier passed.  Printed: median cycles per phase over all waves and slabs, per shape.

@@ -16,7 +16,7 @@ for t in traces:
 rows.sort()
 t0, t1 = rows[0][0], rows[-1][1]
 mid = t0 + (t1 - t0) // 2
-sp = [r for r in rows if "attn_sparse" in r[2] and r[0] >= mid]
+sp = [r for r in rows if ("attn_sparse" in r[2] or "attn_shared" in r[2]) and r[0] >= mid]
 a, b = sp[0][0], sp[-1][1]
 ev = []
 for s, e, _ in rows:

@@ -23,7 +23,7 @@ def read(path, counter, kernel):
 
 
 fetch, write, clips, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-kernel = sys.argv[5] if len(sys.argv) > 5 else "attn_sparse_kernel"
+kernel = sys.argv[5] if len(sys.argv) > 5 else "attn_shared_kernel"
 ft, fk = read(fetch, "FETCH_SIZE", kernel)
 wt, wk = read(write, "WRITE_SIZE", kernel)
 doc = {
