@@ -137,8 +137,8 @@ class MultiLatentEpipolarAdaptor(nn.Module, _Prepared):
                       g=_dev_f32(ff[0].weight), b=_dev_f32(ff[0].bias), w1=pack.pack_linear(ff[1].weight), w2=pack.pack_linear(ff[3].weight))
             if attn.num_register_tokens > 0:   # register K/V do not depend on the input (epipolar.py:86-90)
                 reg = attn.register_tokens[0].float()
-                lp["kreg"] = (reg @ attn.to_k.weight.float().t()).to(torch.bfloat16).contiguous()
-                lp["vreg"] = (reg @ attn.to_v.weight.float().t()).to(torch.bfloat16).contiguous()
+                lp["kreg"] = (reg @ attn.to_k.weight.float().t()).to(ops.BF16).contiguous()
+                lp["vreg"] = (reg @ attn.to_v.weight.float().t()).to(ops.BF16).contiguous()
             pk["layers"].append(lp)
         # per-frame embedding: parameters only -> through the output projection once (adaptors.py:170-178; proj_out is
         # linear, so proj_out(latents + e_f) = proj_out(latents) + W e_f)

@@ -29,20 +29,30 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+VARIANTS = {            # library -> (object directory, extra compile flags)
+    "libccv_hip.so": ("build", []),                                   # bf16 MFMA operands (the default)
+    "libccv_hip_f16.so": ("build_f16", ["-DCCV_OPERANDS_F16"]),       # fp16 MFMA operands (CCV_OPERANDS=f16; csrc/ccv_common.h: ccv_opnd_t)
+}
+
+
+def build(force=False, verbose=False, variants=None):
+    """Compile every variant of the library (all sources of all variants in one pool).  Returns the default library's path."""
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
-            jobs.append((s, o))
+    for libname, (objsub, extra) in VARIANTS.items():
+        if variants is not None and libname not in variants:
+            continue
+        objdir = os.path.join(HERE, objsub)
+        os.makedirs(objdir, exist_ok=True)
+        for src in SOURCES:
+            s = os.path.join(CSRC, src)
+            o = os.path.join(objdir, src.replace(".hip", ".o"))
+            if force or _stale(o, [s] + HEADERS):
+                jobs.append((s, o, extra))
 
     def compile_one(job):
-        s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        s, o, extra = job
+        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -53,16 +63,21 @@ def build(force=False, verbose=False):
         return o
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        jobs.sort(key=lambda j: -os.path.getsize(j[0]))          # the long compiles (ccv_gemm.hip: ~4 min) first
+        with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) - 2), len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    for libname, (objsub, _) in VARIANTS.items():
+        if variants is not None and libname not in variants:
+            continue
+        objs = [os.path.join(HERE, objsub, s.replace(".hip", ".o")) for s in SOURCES]
+        lib = os.path.join(HERE, libname)
+        if force or _stale(lib, objs):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

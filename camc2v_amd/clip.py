@@ -109,13 +109,13 @@ class Transformer(nn.Module, _Prepared):
         dev = qkv.device
         key_bias = torch.zeros(Lp, dtype=torch.float32, device=dev)
         key_bias[L:] = -1e30
-        out = torch.empty((B * L, C), dtype=torch.bfloat16, device=dev)
+        out = torch.empty((B * L, C), dtype=ops.BF16, device=dev)
         q_all = qkv[:, :H * dp]
         k_all = qkv[:, H * dp:2 * H * dp].view(B, L, H, dp)
         v_all = qkv[:, 2 * H * dp:2 * H * dp + C].view(B, L, H, d)
-        k_pad = torch.zeros((B, H, Lp, dp), dtype=torch.bfloat16, device=dev)
+        k_pad = torch.zeros((B, H, Lp, dp), dtype=ops.BF16, device=dev)
         k_pad[:, :, :L] = k_all.permute(0, 2, 1, 3)
-        vt_pad = torch.zeros((B, H, d, Lp), dtype=torch.bfloat16, device=dev)
+        vt_pad = torch.zeros((B, H, d, Lp), dtype=ops.BF16, device=dev)
         vt_pad[:, :, :, :L] = v_all.permute(0, 2, 3, 1)
         for b in range(B):
             rows = slice(b * L, (b + 1) * L)
@@ -183,7 +183,7 @@ class VisionTransformer(nn.Module, _Prepared):
             raise CcvError(f"VisionTransformer: image {tuple(img.shape[-2:])}, expected {(gh * p, gw * p)}")
         patches = img.float().reshape(B, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, 3 * p * p)
         kp = pk["w_patch"].shape[1]
-        a = torch.zeros((B * gh * gw, kp), dtype=torch.bfloat16, device=img.device)
+        a = torch.zeros((B * gh * gw, kp), dtype=ops.BF16, device=img.device)
         a[:, :3 * p * p] = patches
         emb = ops.gemm(a, pk["w_patch"], out_f32=True)[:, :C]                                   # conv1 as a GEMM over the patches
         L = gh * gw + 1

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
                     for (int s = 0; s < 4; ++s) {
                         const int c = 2 * s + hh;
                         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * K_ROW + ((c ^ ((krow >> 1) & 7)) << 4));
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+                        sacc[kb] = ccv_mfma_32x32x16(kf, qf[s], sacc[kb]);
                     }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (__bf16)pv[8 * s2 + j];
+                        for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (ccv_opnd_t)pv[8 * s2 + j];
                 }
                 l_run = l_run * alpha + psum;
 #pragma unroll
@@ -216,10 +216,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
                                 const int li = lane & 15, g = (lane >> 4) & 1;
                                 const int dcol = 32 * d + 16 * g + 4 * (li & 3);
                                 const unsigned char* a0 = sV + (kb0 + (li >> 2)) * V_ROW + dcol * 2;
-                                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                    (__attribute__((address_space(3))) bf16x4*)(a0));
-                                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                    (__attribute__((address_space(3))) bf16x4*)(a0 + 8 * V_ROW));
+                                const bf16x4 lo = ccv_ds_read_tr16(a0);
+                                const bf16x4 hi = ccv_ds_read_tr16(a0 + 8 * V_ROW);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
                             } else {
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
                             }
-                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], oacc[d], 0, 0, 0);
+                            oacc[d] = ccv_mfma_32x32x16(vf, pf[kb][s2], oacc[d]);
                         }
                     }
                 }
@@ -366,7 +364,7 @@ __device__ __forceinline__ void softmax_block32(f32x16& sa, uint32_t w, bool all
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pfo[s2][j] = (__bf16)pv[8 * s2 + j];
+        for (int j = 0; j < 8; ++j) pfo[s2][j] = (ccv_opnd_t)pv[8 * s2 + j];
     l_r += psum2[0] + psum2[1];
 }
 
@@ -575,16 +573,16 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                         for (int s = 0; s < 4; ++s) {
                             const int c = 2 * s + hh;
                             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
-                            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
-                            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
+                            sa0 = ccv_mfma_32x32x16(kf, qf[0][s], sa0);
+                            sa1 = ccv_mfma_32x32x16(kf, qf[1][s], sa1);
                         }
                     } else {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
                             const int c = 2 * s + hh;
                             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
-                            if (on0) sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s], sa0, 0, 0, 0);
-                            else     sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][s], sa1, 0, 0, 0);
+                            if (on0) sa0 = ccv_mfma_32x32x16(kf, qf[0][s], sa0);
+                            else     sa1 = ccv_mfma_32x32x16(kf, qf[1][s], sa1);
                         }
                     }
                     bf16x8 pf0[2], pf1[2];
@@ -604,13 +602,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                             const int colb = (32 * d + 16 * g + 4 * (li & 3)) * 2;  // byte column inside the 128-B row
                             // rows row0 and row0+8 have the same ((row>>1)&1): one swizzle term serves both reads
                             const unsigned char* a0 = sV + row0 * 128 + (colb ^ (((row0 >> 1) & 1) << 6));
-                            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
-                            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 8 * 128));
+                            const bf16x4 lo = ccv_ds_read_tr16(a0);
+                            const bf16x4 hi = ccv_ds_read_tr16(a0 + 8 * 128);
                             bf16x8 vf;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                            if (!MASKED || on0) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf0[s2], oacc[0][d], 0, 0, 0);
-                            if (!MASKED || on1) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf1[s2], oacc[1][d], 0, 0, 0);
+                            if (!MASKED || on0) oacc[0][d] = ccv_mfma_32x32x16(vf, pf0[s2], oacc[0][d]);
+                            if (!MASKED || on1) oacc[1][d] = ccv_mfma_32x32x16(vf, pf1[s2], oacc[1][d]);
                         }
                     }
                 }
@@ -923,10 +921,10 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
             // second chain still runs, so its softmax starts 4 MFMAs earlier
             const bf16x8 kfr[4] = {kf0, kf1, kf2, kf3};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[0][s], sa0, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) sa0 = ccv_mfma_32x32x16(kfr[s], qf[0][s], sa0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[1][s], sa1, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) sa1 = ccv_mfma_32x32x16(kfr[s], qf[1][s], sa1);
         }
         bf16x8 vf[2][2];
         read_vt_block(sV, lane, hh, vf);   // while the score MFMAs run
@@ -939,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int d = 0; d < 2; ++d) oacc[0][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf[s2], oacc[0][d], 0, 0, 0);
+                for (int d = 0; d < 2; ++d) oacc[0][d] = ccv_mfma_32x32x16(vf[s2][d], pf[s2], oacc[0][d]);
         }
         if (on1) {
             bf16x8 pf[2];
@@ -947,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int d = 0; d < 2; ++d) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf[s2], oacc[1][d], 0, 0, 0);
+                for (int d = 0; d < 2; ++d) oacc[1][d] = ccv_mfma_32x32x16(vf[s2][d], pf[s2], oacc[1][d]);
         }
     };
 
@@ -1230,7 +1228,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
             for (int j = 0; j < 4; ++j) { sa[j] = t0[j]; sa[4 + j] = t1[j]; sa[8 + j] = t2[j]; sa[12 + j] = t3[j]; }
             const bf16x8 kfr[4] = {kf0, kf1, kf2, kf3};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sa, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) sa = ccv_mfma_32x32x16(kfr[s], qf[s], sa);
         }
         bf16x8 pf[2];
         softmax_block32(sa, 0xffffffffu, true, hh, sl2, m_run, l_run, oacc, pf);
@@ -1264,7 +1262,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][d], pf[s2], oacc[d], 0, 0, 0);
+            for (int d = 0; d < 2; ++d) oacc[d] = ccv_mfma_32x32x16(vf[s2][d], pf[s2], oacc[d]);
     };
 
     // retire the ordinary vector loads where hipcc can see it (see attn_sparse_kernel)
@@ -1393,7 +1391,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
     // S^T[key 4g + r][query fr]
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+    for (int s = 0; s < 2; ++s) sacc = ccv_mfma_16x16x32(kf[s], qf[s], sacc);
     const float sl2 = p.scale * 1.4426950408889634f;
     float sv[4], m = NEG_INF;
 #pragma unroll
@@ -1404,12 +1402,12 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f;
-    short4_t pb;
+    bf16x4 pb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(sv[r] - m);
         l += e;
-        pb[r] = (short)f32_to_bf16(e);
+        pb[r] = (ccv_opnd_t)e;
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -1420,10 +1418,9 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
         const unsigned char* a0 = &sV[wave][(4 * g + (li >> 2)) * 128 + (16 * dt + 4 * (li & 3)) * 2];
-        const bf16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0));
-        const short4_t va = __builtin_bit_cast(short4_t, vt);
+        const bf16x4 vt = ccv_ds_read_tr16(a0);
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb, o, 0, 0, 0);  // O^T[d = 16 dt + 4 g + r][query fr]
+        o = ccv_mfma_16x16x16(vt, pb, o);  // O^T[d = 16 dt + 4 g + r][query fr]
         if (active && fr < T) {
             uint2 pk = make_uint2(pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv));
             *reinterpret_cast<uint2*>(op + 16 * dt) = pk;

@@ -6,10 +6,51 @@
 
 #include "../../include/ccv.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// The MFMA operand type: bf16 (the default build, libccv_hip.so) or, with -DCCV_OPERANDS_F16 (libccv_hip_f16.so, CCV_OPERANDS=f16;
+// round 4's numerics experiment: the reference itself runs under fp16 autocast, main/trainer.py:193), IEEE half.  Both forms of the
+// MFMA issue at the same rate on gfx950.  Everything below that says "bf16" in its name means "the operand type": the element kind 0
+// of the C ABI, the 16-bit storage format of weights, normalised activations, q / k / v, P and attention outputs.
+#if defined(CCV_OPERANDS_F16)
+typedef _Float16 ccv_opnd_t;
+#else
+typedef __bf16 ccv_opnd_t;
+#endif
+typedef __attribute__((ext_vector_type(8))) ccv_opnd_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) ccv_opnd_t bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ f32x16 ccv_mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(CCV_OPERANDS_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 ccv_mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+#if defined(CCV_OPERANDS_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 ccv_mfma_16x16x16(bf16x4 a, bf16x4 b, f32x4 c) {
+#if defined(CCV_OPERANDS_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+    typedef __attribute__((ext_vector_type(4))) short ccv_short4_t;
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(ccv_short4_t, a), __builtin_bit_cast(ccv_short4_t, b), c, 0, 0, 0);
+#endif
+}
+// ds_read_b64_tr_b16 (the instruction does not care what the 16 bits mean)
+__device__ __forceinline__ bf16x4 ccv_ds_read_tr16(const unsigned char* lds_ptr) {
+#if defined(CCV_OPERANDS_F16)
+    typedef __fp16 ccv_h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) ccv_h4_t*)(lds_ptr)));
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds_ptr));
+#endif
+}
 
 // ---- error plumbing -----------------------------------------------------------------
 void ccv_set_error(const char* fmt, ...);
@@ -32,12 +73,28 @@ void ccv_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- bf16 helpers (raw uint16 storage) ------------------------------------------------
-__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) {
+#if defined(CCV_OPERANDS_F16)
+    return (float)__builtin_bit_cast(_Float16, v);
+#else
+    return __uint_as_float(((uint32_t)v) << 16);
+#endif
+}
 
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
-    __bf16 b = (__bf16)f;
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950 (v_cvt_f16_f32 in the fp16-operand build)
+    ccv_opnd_t b = (ccv_opnd_t)f;
     return __builtin_bit_cast(uint16_t, b);
+}
+// a packed pair of operand elements -> two floats
+__device__ __forceinline__ void ccv_opnd2_to_f32(uint32_t pk, float& lo, float& hi) {
+#if defined(CCV_OPERANDS_F16)
+    typedef __attribute__((ext_vector_type(2))) _Float16 ccv_h2_t;
+    const ccv_h2_t v = __builtin_bit_cast(ccv_h2_t, pk);
+    lo = (float)v[0]; hi = (float)v[1];
+#else
+    lo = __uint_as_float(pk << 16); hi = __uint_as_float(pk & 0xffff0000u);
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -66,7 +123,10 @@ __device__ __forceinline__ float4 ccv_load4(const void* x, long idx4) {
         const float2 a = ccv_unpack_f16x2(u.x), b = ccv_unpack_f16x2(u.y);
         return make_float4(a.x, a.y, b.x, b.y);
     }
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    float4 r;
+    ccv_opnd2_to_f32(u.x, r.x, r.y);
+    ccv_opnd2_to_f32(u.y, r.z, r.w);
+    return r;
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

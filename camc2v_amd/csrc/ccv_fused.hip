@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const CcvFF p) {
             const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             const f16x8 h = frag(ks);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fa[ks][e] = (__bf16)(((float)h[e] - mean) * rstd * gm[e] + bt[e]);
+            for (int e = 0; e < 8; ++e) fa[ks][e] = (ccv_opnd_t)(((float)h[e] - mean) * rstd * gm[e] + bt[e]);
         });
     }
 #pragma unroll
@@ -198,12 +198,12 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const CcvFF p) {
             if constexpr (do_up) {
                 const bf16x8 w0 = wf[ks % PF][0], w1 = wf[ks % PF][1];
                 if constexpr (ks + PF < FF_KS) fetch1(std::integral_constant<int, ks + PF>{}, wf[ks % PF]);
-                cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, fa[ks], cur[0], 0, 0, 0);
-                cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, fa[ks], cur[1], 0, 0, 0);
+                cur[0] = ccv_mfma_32x32x16(w0, fa[ks], cur[0]);
+                cur[1] = ccv_mfma_32x32x16(w1, fa[ks], cur[1]);
             }
             if constexpr (do_gate && ks < 16) {
                 constexpr int f = ks >> 3, e = ks & 7;
-                hf[f][e] = (__bf16)(prev[f][e] * gelu_erf_f(prev[f][8 + e]));
+                hf[f][e] = (ccv_opnd_t)(prev[f][e] * gelu_erf_f(prev[f][8 + e]));
             }
         });
         if constexpr (do_gate) {
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const CcvFF p) {
                 constexpr int nf = decltype(N)::value;
                 const bf16x8 w0 = wd[nf % PD][0], w1 = wd[nf % PD][1];
                 if constexpr (nf + PD < FF_NF) fetch2(std::integral_constant<int, nf + PD>{}, wd[nf % PD]);
-                out[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, hf[0], out[nf], 0, 0, 0);
-                out[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, hf[1], out[nf], 0, 0, 0);
+                out[nf] = ccv_mfma_32x32x16(w0, hf[0], out[nf]);
+                out[nf] = ccv_mfma_32x32x16(w1, hf[1], out[nf]);
             });
         }
     };

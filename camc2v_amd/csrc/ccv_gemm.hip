@@ -220,8 +220,8 @@ __device__ __forceinline__ uint2 round_pack(const CcvGemm& p, float o[4]) {
         o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
     } else {
         pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-        o[0] = __uint_as_float(pk.x << 16); o[1] = __uint_as_float(pk.x & 0xffff0000u);
-        o[2] = __uint_as_float(pk.y << 16); o[3] = __uint_as_float(pk.y & 0xffff0000u);
+        ccv_opnd2_to_f32(pk.x, o[0], o[1]);
+        ccv_opnd2_to_f32(pk.y, o[2], o[3]);
     }
     return pk;
 }
@@ -238,8 +238,8 @@ __device__ __forceinline__ void store_rounded(const CcvGemm& p, int m, int n, fl
     } else {
         const uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
         *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + n) = pk;
-        o[0] = __uint_as_float(pk.x << 16); o[1] = __uint_as_float(pk.x & 0xffff0000u);
-        o[2] = __uint_as_float(pk.y << 16); o[3] = __uint_as_float(pk.y & 0xffff0000u);
+        ccv_opnd2_to_f32(pk.x, o[0], o[1]);
+        ccv_opnd2_to_f32(pk.y, o[2], o[3]);
     }
 }
 
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const CcvGemm p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     // weights as the MFMA A operand (rows = n), activations as B (cols = m)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = ccv_mfma_16x16x32(fb[j], fa[i], acc[i][j]);
         }
         if (s + 1 < s_end) store_slab(buf ^ 1);
         __syncthreads();
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = ccv_mfma_16x16x32(fb[j], fa[i], acc[i][j]);
         }
     };
     if constexpr (ST == 2) {
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sB + lds_off<32>(wn * 16 * NT + 16 * j + fr, fg));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = ccv_mfma_16x16x32(fb, fa[i], acc[i][j]);
         }
     }
 
@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
             for (int i = 0; i < MT; ++i) {
                 const f16x8 h = frag(ks, i);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fa[ks][i][e] = (__bf16)(((float)h[e] - mean[i]) * rstd[i] * gm[e] + bt[e]);
+                for (int e = 0; e < 8; ++e) fa[ks][i][e] = (ccv_opnd_t)(((float)h[e] - mean[i]) * rstd[i] * gm[e] + bt[e]);
             }
         });
     } else {
@@ -1848,7 +1848,7 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks & 1][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = ccv_mfma_16x16x32(fb[ks & 1][j], fa[ks][i], acc[i][j]);
         });
         if (stamps) {   // after the MFMAs have produced their results (reading an accumulator waits for them)
             asm volatile("" ::"v"(acc[MT - 1][NT - 1]));
@@ -1918,10 +1918,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const CcvGemm p) {
                     const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.A) + (long)m * p.lda + 8 * c);
                     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        a[m][2 * q] = __uint_as_float(w[q] << 16);
-                        a[m][2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
-                    }
+                    for (int q = 0; q < 4; ++q) ccv_opnd2_to_f32(w[q], a[m][2 * q], a[m][2 * q + 1]);
                 }
             } else {
 #pragma unroll
@@ -1934,10 +1931,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const CcvGemm p) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             float wf[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wf[2 * q] = __uint_as_float(w[q] << 16);
-                wf[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
-            }
+            for (int q = 0; q < 4; ++q) ccv_opnd2_to_f32(w[q], wf[2 * q], wf[2 * q + 1]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll

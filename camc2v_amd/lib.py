@@ -7,7 +7,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CCV_HIP_LIB") or os.path.join(_HERE, "libccv_hip.so")    # CCV_HIP_LIB: another build of the library (A/B runs)
+# CCV_OPERANDS=f16: the build whose MFMA operand type (element kind 0 of the C ABI) is IEEE half instead of bf16 (round 4's numerics
+# experiment, csrc/ccv_common.h: ccv_opnd_t); the Python side then types operand tensors torch.float16 (ops.BF16)
+OPERANDS = os.environ.get("CCV_OPERANDS", "bf16")
+if OPERANDS not in ("bf16", "f16"):
+    raise ValueError(f"CCV_OPERANDS must be bf16 or f16, got {OPERANDS!r}")
+LIB_NAME = "libccv_hip.so" if OPERANDS == "bf16" else "libccv_hip_f16.so"
+LIB_PATH = os.environ.get("CCV_HIP_LIB") or os.path.join(_HERE, LIB_NAME)    # CCV_HIP_LIB: another build of the library (A/B runs)
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

@@ -10,9 +10,10 @@ import threading
 
 import torch
 
+from . import lib as _lib_mod
 from .lib import CcvAttn, CcvError, CcvFF, CcvGemm, check, lib
 
-BF16 = torch.bfloat16
+BF16 = torch.bfloat16 if _lib_mod.OPERANDS == "bf16" else torch.float16     # the MFMA operand type: element kind 0 of the C ABI (lib.OPERANDS)
 F32 = torch.float32
 F16 = torch.float16      # the residual stream's hand-off format between UNet blocks (arithmetic stays fp32 inside the kernels)
 _KIND = {BF16: 0, F32: 1, F16: 2}      # element-kind codes of the C ABI (include/ccv.h)
@@ -195,7 +196,8 @@ def gemm(a, w, *, n_out=None, k=None, taps=1, lda=None, m=None, bias=None, bias2
         if not ok:
             raise CcvError(f"gemm: bias2 must hold {nb2} fp32 rows of >= {N} columns, ldb2 = {ldb2} apart")
     p.rows_per_batch = rows_per_batch
-    p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), {BF16: 0, F32: 1, F16: 2}[out_dtype], alpha
+    # (fp16-operand build: BF16 is F16, a two-byte output is kind 2 -- the same bits as kind 0 -- except where the C side asks for kind 0)
+    p.act, p.geglu, p.out_f32, p.alpha = act, int(geglu), (0 if geglu else {BF16: 0, F32: 1, F16: 2}[out_dtype]), alpha
     if ln is not None and a is ln.x:
         p.ln_gamma, p.ln_beta, p.ln_eps = _ptr(ln.gamma), _ptr(ln.beta), ln.eps
         if not lib().ccv_gemm_ln_fusable(C.byref(p)):          # no prologue for this problem: normalise first

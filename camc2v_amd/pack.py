@@ -5,7 +5,9 @@ tensors in the layout ccv_gemm expects: W [N, taps*K], k index = tap*K + channel
 """
 import torch
 
-BF16 = torch.bfloat16
+from .lib import OPERANDS
+
+BF16 = torch.bfloat16 if OPERANDS == "bf16" else torch.float16      # the MFMA operand type (lib.OPERANDS)
 
 
 def _pad_dim(t, dim, mult):

@@ -164,7 +164,7 @@ class TemporalTransformerBlock(nn.Module, _Prepared):
                 raise CcvError(f"pose encoder: {f} frames exceed temporal_position_encoding_max_len {pk['pe'].shape[0]}")
             tab = pk["pe_rows"].get((f, hw))
             if tab is None:      # frame encoding as an addend table over one clip's rows: row (frame, pixel) -> pe[frame]
-                tab = pk["pe"][:f].to(torch.bfloat16).repeat_interleave(hw, 0).contiguous()
+                tab = pk["pe"][:f].to(ops.BF16).repeat_interleave(hw, 0).contiguous()
                 pk["pe_rows"] = {(f, hw): tab}
             _, n = ops.layernorm(x, pk["g1"], pk["b1n"], addend=tab)
         else:
@@ -172,7 +172,7 @@ class TemporalTransformerBlock(nn.Module, _Prepared):
         qkv = ops.gemm(n, pk["w_qkv"])
         ld = 3 * C
         st = (f * hw * ld, ld, hw * ld)                       # (clip, pixel, frame) strides
-        o = torch.empty((b * f * hw, C), dtype=torch.bfloat16, device=x.device)
+        o = torch.empty((b * f * hw, C), dtype=ops.BF16, device=x.device)
         ops.attention_small(qkv, qkv[:, C:], qkv[:, 2 * C:], B=b * hw, inner=hw, H=H, T=f, head_dim=D, q_str=st, k_str=st, v_str=st,
                             out=o, o_str=(f * hw * C, C, hw * C))
         ops.gemm(o, pk["w_o"], bias=pk["b_o"], residual=x, out_f32=True, out=x)

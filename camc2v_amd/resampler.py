@@ -95,7 +95,7 @@ class Resampler(nn.Module, _Prepared):
             ln = ops.layernorm(lat, lp["g2"], lp["b2"])
             q = ops.gemm(ln, lp["w_q"])
             # keys / values over [image tokens ; latents] of each sample: the two row blocks are projected into one buffer
-            kv = torch.empty((B * Lk, 2 * inner), dtype=torch.bfloat16, device=x.device).view(B, Lk, 2 * inner)
+            kv = torch.empty((B * Lk, 2 * inner), dtype=ops.BF16, device=x.device).view(B, Lk, 2 * inner)
             kv[:, :n] = ops.gemm(xn, lp["w_kv"]).view(B, n, 2 * inner)
             kv[:, n:] = ops.gemm(ln, lp["w_kv"]).view(B, L, 2 * inner)
             kv = kv.view(B * Lk, 2 * inner)

@@ -97,7 +97,7 @@ class AttnBlock(nn.Module, _Prepared):
         n = ops.groupnorm(x, pk["g"], pk["b"], instances=g.n, eps=1e-6, silu=False)
         q = ops.gemm(n, pk["w_q"], bias=pk["b_q"])                          # [(n L), C] bf16
         k = ops.gemm(n, pk["w_k"], bias=pk["b_k"])
-        o = torch.empty((g.n * L, C), dtype=torch.bfloat16, device=x.device)
+        o = torch.empty((g.n * L, C), dtype=ops.BF16, device=x.device)
         for f in range(g.n):
             rows = slice(f * L, (f + 1) * L)
             # V^T [C, L] = W_v [C, C] . n_f^T: the weight is the "activation" operand, the frame's rows are the "weight"
