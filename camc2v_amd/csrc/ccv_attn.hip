@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const CcvAttn p) {
                     }
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (ccv_opnd_t)pv[8 * s2 + j];
+                        pf[kb][s2] = ccv_opnd8(pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3], pv[8 * s2 + 4], pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]);
                 }
                 l_run = l_run * alpha + psum;
 #pragma unroll
@@ -363,8 +362,7 @@ __device__ __forceinline__ void softmax_block32(f32x16& sa, uint32_t w, bool all
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pfo[s2][j] = (ccv_opnd_t)pv[8 * s2 + j];
+        pfo[s2] = ccv_opnd8(pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3], pv[8 * s2 + 4], pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]);
     l_r += psum2[0] + psum2[1];
 }
 
@@ -1402,13 +1400,15 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const CcvAttn p) {
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f;
-    bf16x4 pb;
+    float ev[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sv[r] - m);
-        l += e;
-        pb[r] = (ccv_opnd_t)e;
+        ev[r] = __builtin_amdgcn_exp2f(sv[r] - m);
+        l += ev[r];
     }
+    typedef __attribute__((ext_vector_type(2))) uint32_t ccv_u2_t;
+    const ccv_u2_t pbu = {pack_bf16x2(ev[0], ev[1]), pack_bf16x2(ev[2], ev[3])};
+    const bf16x4 pb = __builtin_bit_cast(bf16x4, pbu);
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;

@@ -98,7 +98,27 @@ __device__ __forceinline__ void ccv_opnd2_to_f32(uint32_t pk, float& lo, float& 
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if defined(CCV_OPERANDS_F16)
+    // the vector form: one v_cvt_pk_f16_f32 (the scalar form becomes two converts + an or)
+    typedef __attribute__((ext_vector_type(2))) _Float16 ccv_h2p_t;
+    const ccv_h2p_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+#else
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
+}
+// eight floats -> one MFMA operand fragment
+__device__ __forceinline__ bf16x8 ccv_opnd8(float f0, float f1, float f2, float f3, float f4, float f5, float f6, float f7) {
+#if defined(CCV_OPERANDS_F16)
+    typedef __attribute__((ext_vector_type(4))) uint32_t ccv_u4_t;
+    const ccv_u4_t u = {pack_bf16x2(f0, f1), pack_bf16x2(f2, f3), pack_bf16x2(f4, f5), pack_bf16x2(f6, f7)};
+    return __builtin_bit_cast(bf16x8, u);
+#else
+    bf16x8 r;      // (element-wise casts: hipcc pairs them into v_cvt_pk_bf16_f32 by itself)
+    r[0] = (ccv_opnd_t)f0; r[1] = (ccv_opnd_t)f1; r[2] = (ccv_opnd_t)f2; r[3] = (ccv_opnd_t)f3;
+    r[4] = (ccv_opnd_t)f4; r[5] = (ccv_opnd_t)f5; r[6] = (ccv_opnd_t)f6; r[7] = (ccv_opnd_t)f7;
+    return r;
+#endif
 }
 
 // ---- fp16 helpers (the residual stream's hand-off format; raw uint16 storage) ---------------------------

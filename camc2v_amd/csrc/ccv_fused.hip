@@ -133,8 +133,10 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const CcvFF p) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.ln_beta + k0), b1 = *reinterpret_cast<const float4*>(p.ln_beta + k0 + 4);
             const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             const f16x8 h = frag(ks);
+            float nv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fa[ks][e] = (ccv_opnd_t)(((float)h[e] - mean) * rstd * gm[e] + bt[e]);
+            for (int e = 0; e < 8; ++e) nv[e] = ((float)h[e] - mean) * rstd * gm[e] + bt[e];
+            fa[ks] = ccv_opnd8(nv[0], nv[1], nv[2], nv[3], nv[4], nv[5], nv[6], nv[7]);
         });
     }
 #pragma unroll

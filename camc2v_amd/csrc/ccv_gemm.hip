@@ -1706,8 +1706,10 @@ __global__ __launch_bounds__(512, 2) void gemm_astat_kernel(const CcvGemm p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const f16x8 h = frag(ks, i);
+                float nv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fa[ks][i][e] = (ccv_opnd_t)(((float)h[e] - mean[i]) * rstd[i] * gm[e] + bt[e]);
+                for (int e = 0; e < 8; ++e) nv[e] = ((float)h[e] - mean[i]) * rstd[i] * gm[e] + bt[e];
+                fa[ks][i] = ccv_opnd8(nv[0], nv[1], nv[2], nv[3], nv[4], nv[5], nv[6], nv[7]);
             }
         });
     } else {
