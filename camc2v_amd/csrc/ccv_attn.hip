@@ -692,6 +692,10 @@ struct SparseArgs {
     float scale;
     int32_t slot, use_xcd_queues;
     const int32_t* wg_order; int32_t wg_order_bs;   // attn_shared_kernel: items (groups of NW * 32 queries) longest first
+    // attn_shared_kernel, key-split items (see the kernel): ranks >= split_rank0 come in `split_parts` parts; workspace = one counter per
+    // split (slice, rank) followed by the parts' partial results
+    int32_t split_rank0, split_parts;
+    uint32_t* split_ctr; float* split_part;
 };
 
 __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p) {
@@ -1019,7 +1023,18 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
 // of every block it visits: 346 half-blocks per group against the 290 needed).  Math per half-block is attn_sparse_kernel's:
 // seeded S^T = K Q^T, in-lane softmax, O^T += V^T P^T.  Items (batch-head slice, query group) come from the same persistent
 // queue, longest first by p.wg_order (ccv_attn_group_order_merged).
+//
+// Key-split items (the tail): the 1280 items of a 32x32-latent launch do not divide over the 1024 resident workgroups -- the queue's
+// makespan is 1.39x the mean load (the last quarter of the items starts when the first workgroups finish), and the 640 items of a
+// 16x16-latent launch leave 384 workgroup slots empty.  The items of rank >= split_rank0 (the shortest ones, handed out last) therefore
+// come in split_parts parts, each walking a contiguous share of the item's schedule.  A part leaves its running (max, sum, O^T
+// accumulators) in the workspace (write-through stores) and takes a ticket from the item's counter; the part that draws the
+// LAST ticket reads the others back (L1-bypassing loads) and merges all parts in part order -- nobody ever waits for anybody, so the
+// persistent grid cannot deadlock, and the merge (max, two products, one sum per value, no contraction) does not depend on who came last:
+// the result is bitwise reproducible.  The counter is reset by the merging part (the workspace is zeroed once by the caller).
 // =================================================================================================
+constexpr int SPLIT_LANE_FLOATS = 36;          // per lane and part: 32 accumulators + running sum + running max + 2 pad (nine 16-byte stores)
+
 constexpr int SHARED_MAX_BLOCKS = 1037;  // schedule entries (16 bits each) per item kept in LDS: Lk <= 32 * 1037 (+ the register-token step)
 
 template <int NW, int S>
@@ -1053,7 +1068,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     const int ppr_ = p.perm_w >> 3;
     const bool perm_pow2 = p.perm_w && (p.perm_hw & (p.perm_hw - 1)) == 0 && (ppr_ & (ppr_ - 1)) == 0;
     const int sh_hw = perm_pow2 ? __builtin_ctz(p.perm_hw) : 0, sh_ppr = perm_pow2 ? __builtin_ctz(ppr_) : 0;
-    const long qitems = (long)nbh * ngroups;
+    const int parts = max(p.split_parts, 1);
+    const int rank0 = parts > 1 ? min(p.split_rank0, ngroups) : ngroups;        // ranks >= rank0 come in `parts` parts
+    const long q_whole = (long)nbh * rank0;
+    const long qitems = q_whole + (long)nbh * (ngroups - rank0) * parts;
     const int lr8 = lane >> 3, pc = lane & 7;
     // this wave's pieces of a block (piece id = wave * PP + t; ids 0-3 are the four 8-row pieces of K, 4-7 those of V) are all K or all V
     const bool wave_k = wave * PP < 4;
@@ -1090,7 +1108,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     __syncthreads();
     const long item = (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)item_word[0]);
     if (item >= qitems) break;
-    const int rank = (int)(item / nbh), bh = (int)(item % nbh);
+    int rank, bh, part = 0, nparts = 1;
+    if (item < q_whole) { rank = (int)(item / nbh); bh = (int)(item % nbh); }
+    else {   // the parts of one (slice, rank) are nbh queue positions apart: they run at the same time on different workgroups
+        const long t = item - q_whole;
+        const int per_rank = nbh * parts;
+        rank = rank0 + (int)(t / per_rank);
+        const int rem = (int)(t % per_rank);
+        part = rem / nbh;
+        bh = rem % nbh;
+        nparts = parts;
+    }
     const int head = bh % p.H, b = bh / p.H;
     const int mb = b % p.mask_nb;
     const int qg = p.wg_order ? p.wg_order[(long)mb * p.wg_order_bs + rank] : rank;
@@ -1268,24 +1296,27 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     for (int s4 = 0; s4 < 4; ++s4) asm volatile("" ::"v"(qf[s4]));
 
     __syncthreads();                                   // the schedule is complete
-    const int n = (int)__builtin_amdgcn_readfirstlane((int)item_word[1]);
+    const int n_all = (int)__builtin_amdgcn_readfirstlane((int)item_word[1]);
+    // this part's share of the schedule: steps [lo, n) (the prologue / loop below index the schedule from `lo`)
+    const int lo = (int)((long)n_all * part / nparts);
+    const int n = (int)((long)n_all * (part + 1) / nparts);
 
     // ---- S-deep ring: steps i .. i+S-2 are in flight or landed while step i is multiplied ----
     int cur_blk[S - 1];                                // block ids of steps i .. i+S-2 (scalars)
 #pragma unroll
     for (int j = 0; j < S - 1; ++j) {
         cur_blk[j] = -2;
-        if (j < n) {
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[j]);
+        if (lo + j < n) {
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched[lo + j]);
             cur_blk[j] = (int)(e & 0xffffu) - 1;
             issue(e, j);
         }
     }
     const uint32_t sched_addr = lds0 + SCHED;
     uint32_t e_next;                                    // entry of the step the next iteration issues (prefetched one step ahead)
-    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e_next) : "v"(sched_addr + 2 * min(S - 1, n - 1)) : "memory");   // (hipcc does not
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e_next) : "v"(sched_addr + 2 * max(min(lo + S - 1, n - 1), 0)) : "memory");   // (hipcc does not
                                                         // track an inline-asm read: without the wait the first step could use the entry before it arrives)
-    int i = 0;
+    int i = lo;
     auto step = [&](auto stc) __attribute__((always_inline)) -> bool {
         constexpr int st = decltype(stc)::value;
         if (i >= n) return false;
@@ -1324,6 +1355,73 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
         if (!go) break;
     }
 
+    if (nparts > 1) {
+        // ---- a part of a key-split item: publish (max, sum, accumulators), take a ticket; the last ticket merges all parts ----
+        const long sidx = (long)(rank - rank0) * nbh + bh;
+        const long lane_f4 = SPLIT_LANE_FLOATS / 4;                               // 16-byte chunks per lane
+        auto area = [&](int q) { return reinterpret_cast<float4*>(p.split_part) + (((sidx * nparts + q) * NW + wave) * lane_f4) * 64 + lane; };
+        // The hand-off uses write-through stores and L1-bypassing loads (sc1) instead of a release / acquire fence pair: a release fence
+        // writes back the XCD's whole L2 and an acquire drops the CU's L1 under the feet of the 15 other waves (measured: the fences ate
+        // most of the split's gain).  MI355X_MICROARCH.md, "Valid forms": every handed-off byte stored sc1, every storing wave drained
+        // (vmcnt(0)) before the workgroup barrier, ONE lane's agent-scope atomic add behind that barrier, the workgroup whose add came
+        // last (told by the returned value) loads -- every load sc1 -- after a barrier that lane has joined.
+        {
+            float4* dst = area(part);                                           // chunk c of lane l at [c][l]: one 1 KiB store per chunk and wave
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 v4 = {oacc[c >> 2][4 * (c & 3)], oacc[c >> 2][4 * (c & 3) + 1], oacc[c >> 2][4 * (c & 3) + 2], oacc[c >> 2][4 * (c & 3) + 3]};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + c * 64), "v"(v4) : "memory");
+            }
+            const f32x4 tail = {l_run, m_run, 0.f, 0.f};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 8 * 64), "v"(tail) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // every storing wave, then the workgroup ...
+        __syncthreads();
+        if (tid == 0) item_word[2] = atomicAdd(p.split_ctr + sidx, 1u);          // ... then ONE lane signals (agent scope, returned value)
+        __syncthreads();
+        const unsigned ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)item_word[2]);
+        if (ticket != (unsigned)(nparts - 1)) continue;                          // somebody else will merge
+        if (tid == 0) p.split_ctr[sidx] = 0u;                                    // for the next launch that uses this workspace
+        // merge in part order (own part from registers): the same arithmetic whoever arrived last
+        float M = NEG_INF, Ls = 0.f;
+        f32x16 om[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) om[d][e] = 0.f;
+        for (int q = 0; q < nparts; ++q) {
+            float mq, lq;
+            const float4* src = area(q);
+            f32x4 got[9];                                                      // the other part's lane slot: nine 16-byte sc1 loads, one wait
+            if (q != part) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(got[c]) : "v"(src + c * 64) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]), "+v"(got[4]), "+v"(got[5]), "+v"(got[6]),
+                             "+v"(got[7]), "+v"(got[8])::"memory");
+            }
+            if (q == part) { mq = m_run; lq = l_run; }
+            else { lq = got[8][0]; mq = got[8][1]; }
+            const float mn = fmaxf(M, mq);
+            const float mu = (mn == NEG_INF) ? 0.f : mn;
+            const float a = __builtin_amdgcn_exp2f(M - mu), bq = __builtin_amdgcn_exp2f(mq - mu);
+            Ls = __fadd_rn(__fmul_rn(Ls, a), __fmul_rn(lq, bq));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                f32x4 t;
+                if (q == part) { t[0] = oacc[c >> 2][4 * (c & 3)]; t[1] = oacc[c >> 2][4 * (c & 3) + 1]; t[2] = oacc[c >> 2][4 * (c & 3) + 2]; t[3] = oacc[c >> 2][4 * (c & 3) + 3]; }
+                else t = got[c];
+                const int d_ = c >> 2, e_ = 4 * (c & 3);
+                om[d_][e_] = __fadd_rn(__fmul_rn(om[d_][e_], a), __fmul_rn(t[0], bq));
+                om[d_][e_ + 1] = __fadd_rn(__fmul_rn(om[d_][e_ + 1], a), __fmul_rn(t[1], bq));
+                om[d_][e_ + 2] = __fadd_rn(__fmul_rn(om[d_][e_ + 2], a), __fmul_rn(t[2], bq));
+                om[d_][e_ + 3] = __fadd_rn(__fmul_rn(om[d_][e_ + 3], a), __fmul_rn(t[3], bq));
+            }
+            M = mn;
+        }
+        oacc[0] = om[0];
+        oacc[1] = om[1];
+        l_run = Ls;
+    }
     {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -1443,6 +1541,82 @@ extern "C" int64_t ccv_attn_sparse_queue_item(int32_t nbh, int32_t ngroups, int3
     return n;
 }
 
+// ---- routing of the masked calls that carry a block bitmap (shared by ccv_attn_fwd and ccv_attn_split_ws_bytes) ----------------------
+static int attn_n_cu() {
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return n_cu;
+}
+static long sparse_pct() {   // persistent workgroups in percent of the CU count (A/B aid; 200 = two 256-thread workgroups of the per-wave kernel per CU)
+    static const long pct = [] { const char* e = getenv("CCV_ATTN_SPARSE_PCT"); const int v = e ? atoi(e) : 200; return (long)(v >= 50 && v <= 200 ? v : 200); }();
+    return pct;
+}
+static bool takes_sparse_path(const CcvAttn& p) {
+    return (p.variant == 0 || p.variant >= 3) && p.k2 == nullptr && p.mask_bits && p.wave_bits &&
+           (p.variant >= 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024);
+}
+// waves per workgroup of the workgroup-shared kernel for this call, 0 = the per-wave kernel.  variant 4 / 5 force the 8- / 4-wave form,
+// variant 6 the per-wave kernel; otherwise CCV_ATTN_SHARED = 4 (default: measured fastest, profiles/r04_sparse_shared_kv.txt) | 8 | 0
+static int shared_waves(const CcvAttn& p) {
+    static const int shared_env = [] { const char* e = getenv("CCV_ATTN_SHARED"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 4) ? v : 0; }();
+    int nw = p.variant == 4 ? 8 : (p.variant == 5 ? 4 : (p.variant == 6 ? 0 : shared_env));
+    if ((p.Lk + 31) / 32 > SHARED_MAX_BLOCKS) nw = 0;   // the item's schedule lives in LDS (16 bits per step): longer key sequences stay on the per-wave kernel
+    return nw;
+}
+struct SplitPlan { int rank0, parts; long n_split, ctr_bytes, total_bytes, slots, items_per; };
+// Key-split plan of the workgroup-shared kernel (see the kernel): T items over P resident workgroups.  T > P (32x32 latents: 1280 over
+// 1024): the ranks that do not fit the first round -- the shortest items -- come in two parts, so the workgroups that finish first share
+// them.  T <= P (16x16 latents: 640 over 1024, 384 slots idle): every item in s parts, s in 1 .. 4 minimising ceil(T s / P) / s (3: two
+// rounds of thirds instead of one round of wholes) -- built and measured slower, so only on request (split_all_parts).  CCV_ATTN_SPLIT=0
+// switches the tail split off (A/B aid); short key sequences are never split.
+static SplitPlan split_plan(const CcvAttn& p, int nw) {
+    static const bool on = [] { const char* e = getenv("CCV_ATTN_SPLIT"); return !(e && e[0] == '0'); }();
+    SplitPlan sp{0, 1, 0, 0, 0, 0, 0};
+    const int merge = nw / 2;
+    const long g64 = (p.Lq + 63) / 64;
+    sp.items_per = (g64 + merge - 1) / merge;
+    const long nbh = (long)p.H * p.B, T = sp.items_per * nbh;
+    const long cap = sparse_pct() * attn_n_cu() / 100 * (nw == 8 ? 1 : 2);     // 2 x 512 or 4 x 256 threads per CU
+    sp.slots = T < cap ? T : cap;
+    sp.rank0 = (int)sp.items_per;
+    if (!on || (p.Lk + 31) / 32 < 96 || T < 64) return sp;
+    if (T > cap) {
+        if (T >= 3 * cap) return sp;                     // many rounds: the tail is a small share
+        sp.rank0 = (int)(cap / nbh);
+        sp.parts = 2;
+    } else {
+        // measured (profiles/r04_sparse_shared_kv.txt): splitting EVERY item of a launch costs more partial-result traffic than the idle slots
+        // are worth (16x16 latents, 3 parts: 108 -> 123 us), so it happens only on request (CcvAttn.split_all_parts; tests, A/B runs)
+        static const int env_all = [] { const char* e = getenv("CCV_ATTN_SPLIT_ALL"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4 ? v : 1; }();
+        const int max_all = p.split_all_parts >= 2 && p.split_all_parts <= 4 ? p.split_all_parts : env_all;
+        int best = 1;
+        double cost = 1.0;
+        for (int s2 = 2; s2 <= max_all; ++s2) {
+            const double c = (double)((T * s2 + cap - 1) / cap) / s2;
+            if (c < cost - 1e-9) { cost = c; best = s2; }
+        }
+        if (best == 1) return sp;
+        sp.rank0 = 0;
+        sp.parts = best;
+        sp.slots = T * best < cap ? T * best : cap;
+    }
+    if (sp.rank0 >= sp.items_per) { sp.rank0 = (int)sp.items_per; sp.parts = 1; return sp; }
+    sp.n_split = (sp.items_per - sp.rank0) * nbh;
+    sp.ctr_bytes = (sp.n_split * 4 + 255) / 256 * 256;
+    sp.total_bytes = sp.ctr_bytes + sp.n_split * sp.parts * nw * 64 * SPLIT_LANE_FLOATS * 4;
+    return sp;
+}
+
+extern "C" int64_t ccv_attn_split_ws_bytes(const CcvAttn* pp) {
+    if (!pp || !takes_sparse_path(*pp)) return 0;
+    const int nw = shared_waves(*pp);
+    if (!nw) return 0;
+    return split_plan(*pp, nw).total_bytes;
+}
+
 static bool two_ctx_on() {   // CCV_ATTN_TWO=0: two-context calls on the first-generation kernel (A/B aid)
     static const bool v = [] { const char* e = getenv("CCV_ATTN_TWO"); return !(e && e[0] == '0'); }();
     return v;
@@ -1502,21 +1676,17 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
         const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
         CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
         dim3 grid2((unsigned)nwg2);
-        if (p.mask_bits && p.wave_bits && (p.variant >= 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024)) {
+        if (takes_sparse_path(p)) {
             // persistent: 2 workgroups per CU (LDS-bound), fewer when there are fewer 64-query groups than waves
             static std::atomic<int> next_slot{0};
             CCV_REQUIRE(p.k_ls >= 0 && p.v_ls >= 0 && (long)p.Lk * p.k_ls < (1l << 31) && (long)p.Lk * p.v_ls < (1l << 31), CCV_ESHAPE,
                         "ccv_attn_fwd: sparse kernel addresses one K/V slice with 32-bit element offsets");
-            static const int n_cu = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                return n;
-            }();
+            const int n_cu = attn_n_cu();
             const int slot = next_slot.fetch_add(1) & 63;   // successive launches use different counter rows; callers whose launches
                                                             // overlap on several streams pass their own zeroed queue_counters
             const long groups = (long)((p.Lq + 63) / 64) * p.H * p.B;
             // persistent workgroups in percent of the CU count (A/B aid; 200 = two per CU = all the LDS)
-            static const long pct = [] { const char* e = getenv("CCV_ATTN_SPARSE_PCT"); const int v = e ? atoi(e) : 200; return (long)(v >= 50 && v <= 200 ? v : 200); }();
+            const long pct = sparse_pct();
             const long cap = pct * n_cu / 100;
             const long wgs = (groups + 3) / 4 < cap ? (groups + 3) / 4 : cap;
             if (!p.queue_counters) hipLaunchKernelGGL(sparse_ctr_reset, dim3(1), dim3(64), 0, st, slot);
@@ -1541,11 +1711,8 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             a.B = p.B; a.inner = p.inner; a.H = p.H; a.Lq = p.Lq; a.Lk = p.Lk; a.nreg = p.kreg ? p.nreg : 0; a.perm_hw = p.perm_hw; a.perm_w = p.perm_w;
             a.scale = p.scale; a.slot = slot; a.use_xcd_queues = xcd_queues;
             a.wg_order = nullptr; a.wg_order_bs = 0;
-            // round 4: K / V blocks shared by the workgroup (attn_shared_kernel).  variant 4 / 5 force the 8- / 4-wave form, variant 6 the
-            // per-wave kernel; otherwise CCV_ATTN_SHARED = 4 (default: measured fastest, profiles/r04_sparse_shared_kv.txt) | 8 | 0 (A/B aid)
-            static const int shared_env = [] { const char* e = getenv("CCV_ATTN_SHARED"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 4) ? v : 0; }();
-            int nw = p.variant == 4 ? 8 : (p.variant == 5 ? 4 : (p.variant == 6 ? 0 : shared_env));
-            if ((p.Lk + 31) / 32 > SHARED_MAX_BLOCKS) nw = 0;   // the item's schedule lives in LDS (16 bits per step): longer key sequences stay on the per-wave kernel
+            a.split_rank0 = 0; a.split_parts = 1; a.split_ctr = nullptr; a.split_part = nullptr;
+            const int nw = shared_waves(p);      // round 4: K / V blocks shared by the workgroup (attn_shared_kernel)
             if (nw) {
                 const int merge = nw / 2;                         // 64-query groups per item
                 const long g64 = (p.Lq + 63) / 64, items_per = (g64 + merge - 1) / merge;
@@ -1553,9 +1720,17 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
                     CCV_REQUIRE(p.wg_order_bs >= items_per && p.wg_order_bs < (1l << 31), CCV_EINVAL, "ccv_attn_fwd: wg_order_bs too small");
                     a.wg_order = p.wg_order; a.wg_order_bs = (int32_t)p.wg_order_bs;
                 }
+                // key-split tail (split_plan): needs the caller's workspace (ccv_attn_split_ws_bytes; counters zeroed once, self-cleaning)
+                const SplitPlan sp = split_plan(p, nw);
+                if (sp.parts > 1 && p.split_ws != nullptr && p.split_ws_bytes >= sp.total_bytes) {
+                    a.split_rank0 = sp.rank0; a.split_parts = sp.parts;
+                    a.split_ctr = static_cast<uint32_t*>(p.split_ws);
+                    a.split_part = reinterpret_cast<float*>(static_cast<unsigned char*>(p.split_ws) + sp.ctr_bytes);
+                }
                 const long items = items_per * p.H * p.B;
                 const long cap_s = pct * n_cu / 100 * (nw == 8 ? 1 : 2);   // 2 x 512 or 4 x 256 threads per CU
-                const long wgs_s = items < cap_s ? items : cap_s;
+                const long work = a.split_parts > 1 ? (long)sp.rank0 * p.H * p.B + sp.n_split * sp.parts : items;
+                const long wgs_s = work < cap_s ? work : cap_s;
                 static const int ring_s = [] { const char* e = getenv("CCV_ATTN_SHARED_S"); const int v = e ? atoi(e) : 4; return (v >= 3 && v <= 5) ? v : 4; }();   // ring depth (A/B aid)
                 if (nw == 8) {
                     if (ring_s == 3)      hipLaunchKernelGGL((attn_shared_kernel<8, 3>), dim3((unsigned)wgs_s), dim3(512), 0, st, a);

@@ -65,6 +65,7 @@ class CcvAttn(C.Structure):
         ("variant", i32),
         ("queue_counters", vp),
         ("wg_order", vp), ("wg_order_bs", i64), ("wg_merge", i32),
+        ("split_ws", vp), ("split_ws_bytes", i64), ("split_all_parts", i32),
     ]
 
 
@@ -82,6 +83,7 @@ SIGNATURES = {
     "ccv_ff_fused": (i32, [C.POINTER(CcvFF), vp]),
     "ccv_groupnorm_apply_parts": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]),
     "ccv_attn_fwd": (i32, [C.POINTER(CcvAttn), vp]),
+    "ccv_attn_split_ws_bytes": (i64, [C.POINTER(CcvAttn)]),
     "ccv_groupnorm_ws_bytes": (i64, [i32, i32]),
     "ccv_groupnorm_chunks": (i32, [i32, i32, i32]),
     "ccv_groupnorm_single_launch": (i32, [i32, i32, i32, i32]),

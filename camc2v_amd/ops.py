@@ -328,13 +328,28 @@ def _queue_counters(device):
     return torch.zeros(8, dtype=torch.int32, device=device)
 
 
+SPARSE_SPLIT = True   # False: no key-split items (tests / A-B aid; split=False per call does the same)
+_SPLIT_WS = {}        # (device, stream) -> zeroed uint8 workspace of the sparse kernel's key-split items (grown on demand)
+
+
+def _split_workspace(device, nbytes):
+    """The calls of one stream run one after the other and every launch leaves the counters at zero again, so one buffer per stream
+    serves them all; another stream (a second clip in flight) gets its own."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLIT_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _SPLIT_WS[key] = ws
+    return ws
+
+
 SPARSE_PROBE = None   # a list: attention() appends (start event, end event, Lq, H, B) per sparse-kernel launch (eager mode only)
 
 
 def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_str=None, scale=None,
               k2=None, v2=None, k2_str=None, v2_str=None, Lk2=0, gate2=1.0,
               mask_bits=None, mask_nb=1, tile_flags=None, wave_bits=None, group_order=None, kreg=None, vreg=None, variant=None,
-              perm=None):
+              perm=None, split=True, split_all=0):
     """Fused attention, head dim 64.  *_str = (batch_outer, batch_inner, token) strides in elements;
     q/k/v are bf16 tensors whose data_ptr() is the element (batch 0, token 0, head 0, d 0).
     Returns bf16 [B*Lq, H*64] unless `out`/`o_str` are given."""
@@ -398,6 +413,12 @@ def attention(q, k, v, *, B, inner, H, Lq, Lk, q_str, k_str, v_str, out=None, o_
     # sparse kernel (same rule as csrc/ccv_attn.hip: block bitmap given and variant 3 or >= 1024 64-query groups)
     probe = SPARSE_PROBE if (wave_bits is not None and mask_bits is not None
                              and (p.variant >= 3 or ((Lq + 63) // 64) * H * B >= 1024)) else None
+    p.split_all_parts = int(split_all)
+    if wave_bits is not None and mask_bits is not None and split and SPARSE_SPLIT:
+        need = lib().ccv_attn_split_ws_bytes(C.byref(p))
+        if need > 0:      # key-split tail of the workgroup-shared sparse kernel: one zeroed, self-cleaning workspace per stream
+            ws = _split_workspace(q.device, need)
+            p.split_ws, p.split_ws_bytes = _ptr(ws), ws.numel()
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -238,8 +238,19 @@ typedef struct CcvAttn {
                               * 64-query groups whose K / V blocks one workgroup stages once: 4 for its 8-wave form, 2 for the
                               * 4-wave form) by decreasing size of the union of their needed key blocks.  NULL or another
                               * wg_merge than the kernel's: items are handed out in index order (same result, longer tail). */
+    void* split_ws; int64_t split_ws_bytes; /* NULL or >= ccv_attn_split_ws_bytes(p) bytes whose first bytes (the counters: the whole
+                              * buffer may simply be zeroed) the caller ZEROED once before its first use on `stream`: workspace of the
+                              * workgroup-shared sparse kernel's key-split items (the shortest items come in 2-4 parts so that the
+                              * persistent workgroups finish together; the part that finishes last merges them and resets its counter, so
+                              * one buffer serves every later call on the same stream).  NULL / too small: no item is split. */
+    int32_t split_all_parts; /* 0: only the queue's tail is split (launches with more items than resident workgroups).  2 .. 4: a launch
+                              * that leaves workgroup slots empty may also split EVERY item into up to that many parts (measured
+                              * slower at the benchmark's sizes; kept for tests and A/B runs) */
 } CcvAttn;
 int ccv_attn_fwd(const CcvAttn* p, void* stream);
+/* Bytes of CcvAttn.split_ws this call would use on the current device (0: the call does not take the workgroup-shared sparse kernel, or
+ * its items divide well enough over the chip).  Replaces nothing in the reference (scheduling aid of epipolar.py:75-102's attention). */
+int64_t ccv_attn_split_ws_bytes(const CcvAttn* p);
 /* Self-attention over Lq = Lk <= 16 tokens with an arbitrary head width (multiple of 8, <= 256): the temporal blocks of
  * CameraPoseEncoder (model/modules/camera_pose_encoder.py:15-158; heads of 40 / 80 / 160 channels).  Uses q/k/v/o with
  * their strides, B, inner, H, Lq, scale of CcvAttn; the head h of a token starts at column h * head_dim.  No masks. */

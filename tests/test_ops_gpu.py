@@ -34,6 +34,15 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.bfloat16):
     return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
 
 
+def ccv_patch_row_py(idx, hw, w):
+    """camc2v_amd/csrc/ccv_common.h: ccv_patch_row (token index in 4x8-patch order -> stored raster row)."""
+    f, rem = divmod(idx, hw)
+    patch, within = rem >> 5, rem & 31
+    ppr = w >> 3
+    py, px = divmod(patch, ppr)
+    return f * hw + (py * 4 + (within >> 3)) * w + px * 8 + (within & 7)
+
+
 L2_REPORT = os.environ.get("CCV_TEST_L2_REPORT")     # a file: every comparison's (what, tol, rel-L2) is appended (bound-setting aid)
 
 
@@ -508,6 +517,7 @@ def test_attention_shared_kv_kernel(ops, L, H, density, perm):
     st = (L * ld, 0, ld)
     kw = dict(B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st, mask_bits=bits, mask_nb=1, tile_flags=flags, wave_bits=mp.wave_bits,
               kreg=kreg, vreg=vreg, perm=perm)
+    kw["split"] = False          # key-split items have a test of their own below
     per_wave = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=6, group_order=mp.group_order, **kw)
     x = qkv.float().reshape(B, L, 3, H, 64)
     k = torch.cat([kreg.float().reshape(1, nreg, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)
@@ -525,6 +535,59 @@ def test_attention_shared_kv_kernel(ops, L, H, density, perm):
     a = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=6, group_order=mp.group_order, **kw2)
     b4 = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], variant=4, group_order=mp.group_order, **kw2)
     assert torch.equal(a, b4)
+
+
+@pytest.mark.parametrize("T,hl,H,B,split_all", [(16, 16, 5, 2, 4),      # 640 items over 1024 workgroup slots: on request every item in 3 parts
+                                                (16, 32, 5, 2, 0),      # 1280 items: the 260 shortest in 2 parts (the default rule)
+                                                (12, 16, 3, 1, 4)])     # 72 items: on request 4 parts
+def test_attention_shared_kernel_key_split_items(ops, T, hl, H, B, split_all):
+    """Key-split items of the workgroup-shared sparse kernel (the queue's tail in 2-4 parts, merged by the part that finishes last):
+    against the unsplit kernel within ONE bf16 rounding realisation (a part rounds its P = exp2(s - m) against its own running maximum,
+    so the products are another rounding of the same numbers: rel-L2 ~ 2e-3, not bit for bit; against torch fp32 the split and the
+    whole result are equally close), bitwise reproducible from launch to launch although the merging workgroup is whoever arrives
+    last, the workspace's counters back at zero, and unchanged results when the same workspace is reused by calls of other sizes."""
+    from camc2v_amd import camera
+    dev_ = dev()
+    px = 8 * hl
+    K = torch.tensor([[px / 2, 0, px / 2], [0, px / 2, px / 2], [0, 0, 1.0]], device=dev_).repeat(1, T, 1, 1)
+    w2c = camera.synthetic_trajectory(1, T, dev_)
+    Fm = camera.pairwise_fundamental(K, camera.relative_c2w(w2c, torch.zeros(1, dtype=torch.long, device=dev_)),
+                                     generator=torch.Generator(device=dev_).manual_seed(9))
+    mp = ops.epipolar_mask_bits(Fm, T, hl, hl, 8, patch_order=True)
+    L, C = T * hl * hl, H * 64
+    qkv = rnd(B * L, 3 * C, seed=140)
+    kreg = rnd(4, C, seed=141)
+    st = (L * 3 * C, 0, 3 * C)
+    kw = dict(B=B, inner=1, H=H, Lq=L, Lk=L, q_str=st, k_str=st, v_str=st, mask_bits=mp[0], mask_nb=1, tile_flags=mp[1], wave_bits=mp.wave_bits,
+              group_order=mp.group_order, kreg=kreg, vreg=kreg, perm=(hl * hl, hl), variant=5, split_all=split_all)
+    whole = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], split=False, **kw)
+    key = (dev_, torch.cuda.current_stream(dev_).cuda_stream)
+    ops._SPLIT_WS.pop(key, None)
+    outs = [ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **kw).clone() for _ in range(3)]
+    assert key in ops._SPLIT_WS, "this problem is expected to split (ccv_attn_split_ws_bytes > 0)"
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "key-split result is not reproducible"
+    assert_close(outs[0], whole, 1e-2, f"key-split vs whole items T={T} {hl}x{hl}", l2=4e-3)
+    if L <= 4096:      # both against fp32 attention: the same distance
+        x = qkv.float().reshape(B, L, 3, H, 64)
+        kk = torch.cat([kreg.float().reshape(1, 4, H, 64).expand(B, -1, -1, -1), x[:, :, 1]], 1)
+        vv = torch.cat([kreg.float().reshape(1, 4, H, 64).expand(B, -1, -1, -1), x[:, :, 2]], 1)
+        shifts = torch.arange(32, device=dev_, dtype=torch.int32)
+        dense = ((mp[0].unsqueeze(-1) >> shifts) & 1).bool().reshape(1, L, -1)[:, :, :L]      # rows / columns in patch order
+        order = torch.tensor([ccv_patch_row_py(i, hl * hl, hl) for i in range(L)], device=dev_)
+        raster = torch.zeros((L, L), dtype=torch.bool, device=dev_)
+        raster[order[:, None], order[None, :]] = dense[0]          # entry (i, j) of the patch-ordered mask belongs to stored rows order[i], order[j]
+        m = F.pad(raster[None].expand(B, -1, -1), (4, 0), value=True)
+        ref = ref_attn(x[:, :, 0], kk, vv, m)
+        for o, what in ((outs[0], "key-split"), (whole, "whole items")):
+            assert_close(o.reshape(B, L, H, 64), ref, 1.5e-2, f"{what} vs torch fp32, T={T} {hl}x{hl}")
+    torch.cuda.synchronize()
+    ws = ops._SPLIT_WS[key]
+    assert int(ws[:256].view(torch.int32).abs().sum()) == 0, "the merging parts must leave the counters at zero"      # (>= 64 counters in every case here)
+    # a call of another size reuses (or grows) the same workspace; then this one again: unchanged
+    small = dict(kw, B=1)
+    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **small)
+    again = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **kw)
+    assert torch.equal(again, outs[0])
 
 
 @pytest.mark.parametrize("fh,fw", [(8, 16), (12, 24)])
