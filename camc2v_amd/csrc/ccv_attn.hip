@@ -1605,7 +1605,10 @@ static SplitPlan split_plan(const CcvAttn& p, int nw) {
     }
     if (sp.rank0 >= sp.items_per) { sp.rank0 = (int)sp.items_per; sp.parts = 1; return sp; }
     sp.n_split = (sp.items_per - sp.rank0) * nbh;
-    sp.ctr_bytes = (sp.n_split * 4 + 255) / 256 * 256;
+    // the counters live in a FIXED prefix of the workspace: calls of different sizes share one buffer (one per stream), and a smaller
+    // call's partial results must never land on a larger call's (zero, self-cleaning) counters
+    sp.ctr_bytes = 65536;
+    if (sp.n_split * 4 > sp.ctr_bytes) { sp.rank0 = (int)sp.items_per; sp.parts = 1; sp.n_split = 0; sp.ctr_bytes = 0; return sp; }
     sp.total_bytes = sp.ctr_bytes + sp.n_split * sp.parts * nw * 64 * SPLIT_LANE_FLOATS * 4;
     return sp;
 }

@@ -12,7 +12,7 @@ import torch.nn as nn
 from . import rng
 from .config import instantiate_from_config
 from .lib import CcvError
-from .sampler import DDIMSampler, make_beta_schedule
+from .sampler import DDIMSampler, make_beta_schedule, rescale_zero_terminal_snr
 
 
 class DiffusionWrapper(nn.Module):
@@ -44,7 +44,7 @@ class LatentDiffusionCore(nn.Module):
 
     def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
                  cosine_s=8e-3, parameterization="eps", conditioning_key=None, channels=3, image_size=256,
-                 temporal_length=None, use_dynamic_rescale=False, rescale_betas_zero_snr=False,
+                 temporal_length=None, use_dynamic_rescale=False, rescale_betas_zero_snr=False, base_scale=0.7, turning_step=400,
                  first_stage_config=None, scale_factor=1.0, perframe_ae=False, encoder_type="2d", **ignored):
         super().__init__()
         # first-stage decoder: optional -- the DDIM path itself never touches it
@@ -53,16 +53,20 @@ class LatentDiffusionCore(nn.Module):
             self.first_stage_model = instantiate_from_config(first_stage_config).eval()
             for p_ in self.first_stage_model.parameters():
                 p_.requires_grad = False
-        if parameterization != "eps" or use_dynamic_rescale or rescale_betas_zero_snr:
-            raise NotImplementedError("only eps-parameterised, statically scaled schedules are shipped")
+        if parameterization not in ("eps", "v"):
+            raise NotImplementedError("x0 parameterisation has no sampling path in the reference's DDIMSampler either")
+        # the shipped configs are eps-parameterised with a static scale; "v", use_dynamic_rescale and rescale_betas_zero_snr
+        # (lvdm/models/ddpm3d.py:75,130-134,524-529) run the sampler's general (torch) step instead of the fused HIP step
         self.parameterization = parameterization
-        self.use_dynamic_rescale = False
+        self.use_dynamic_rescale = bool(use_dynamic_rescale)
         self.channels = channels
         self.image_size = image_size if isinstance(image_size, (list, tuple)) else [image_size, image_size]
         self.model = DiffusionWrapper(unet_config, conditioning_key)
         self.temporal_length = temporal_length if temporal_length is not None else getattr(
             self.model.diffusion_model, "temporal_length", None)
         betas = make_beta_schedule(beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+        if rescale_betas_zero_snr:
+            betas = rescale_zero_terminal_snr(betas)
         ac = np.cumprod(1.0 - betas, axis=0)
         self.num_timesteps = int(timesteps)
         f32 = lambda a: torch.tensor(a, dtype=torch.float32)
@@ -71,6 +75,9 @@ class LatentDiffusionCore(nn.Module):
         self.register_buffer("alphas_cumprod_prev", f32(np.append(1.0, ac[:-1])))
         self.register_buffer("sqrt_alphas_cumprod", f32(np.sqrt(ac)))
         self.register_buffer("sqrt_one_minus_alphas_cumprod", f32(np.sqrt(1.0 - ac)))
+        if self.use_dynamic_rescale:      # ddpm3d.py:524-529
+            scale_arr = np.concatenate((np.linspace(1.0, base_scale, turning_step), np.full(self.num_timesteps, base_scale)))
+            self.register_buffer("scale_arr", f32(scale_arr))
 
     @property
     def device(self):
@@ -81,6 +88,15 @@ class LatentDiffusionCore(nn.Module):
         shape = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
         return (self.sqrt_alphas_cumprod[t].reshape(shape) * x_start
                 + self.sqrt_one_minus_alphas_cumprod[t].reshape(shape) * noise)
+
+    def _extract(self, table, t, x):
+        return table[t].reshape((x.shape[0],) + (1,) * (x.dim() - 1))
+
+    def predict_start_from_z_and_v(self, x_t, t, v):          # ddpm3d.py:241-247
+        return self._extract(self.sqrt_alphas_cumprod, t, x_t) * x_t - self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_t) * v
+
+    def predict_eps_from_z_and_v(self, x_t, t, v):            # ddpm3d.py:249-253
+        return self._extract(self.sqrt_alphas_cumprod, t, x_t) * v + self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_t) * x_t
 
     def _as_dict(self, cond):
         if isinstance(cond, dict):

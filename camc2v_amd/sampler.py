@@ -36,6 +36,17 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2,
     raise ValueError(f"schedule '{schedule}' unknown.")
 
 
+def rescale_zero_terminal_snr(betas):
+    """Betas with zero terminal SNR (lvdm/models/utils_diffusion.py:112-144, arXiv 2305.08891 algorithm 1): sqrt(alpha_bar) shifted so
+    that the last step is zero and scaled so that the first keeps its value."""
+    ab_sqrt = np.sqrt(np.cumprod(1.0 - betas, axis=0))
+    first, last = ab_sqrt[0].copy(), ab_sqrt[-1].copy()
+    ab_sqrt = (ab_sqrt - last) * (first / (first - last))
+    ab = ab_sqrt ** 2
+    alphas = np.concatenate([ab[0:1], ab[1:] / ab[:-1]])
+    return 1.0 - alphas
+
+
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
     if ddim_discr_method == "uniform":
         c = num_ddpm_timesteps // num_ddim_timesteps
@@ -338,8 +349,9 @@ class DDIMSampler(object):
         self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
         ac = self.model.alphas_cumprod
         assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
-        if getattr(self.model, "use_dynamic_rescale", False):
-            raise NotImplementedError("use_dynamic_rescale is not used by any shipped config")
+        if getattr(self.model, "use_dynamic_rescale", False):      # ddim.py:31-33
+            self.ddim_scale_arr = self.model.scale_arr[torch.as_tensor(np.ascontiguousarray(self.ddim_timesteps), device=self.model.scale_arr.device)]
+            self.ddim_scale_arr_prev = torch.cat([self.ddim_scale_arr[0:1], self.ddim_scale_arr[:-1]])
         f32 = lambda t: t.detach().clone().float()
         self.register_buffer("betas", f32(self.model.betas))
         self.register_buffer("alphas_cumprod", f32(ac))
@@ -382,18 +394,22 @@ class DDIMSampler(object):
         (parity tests; the reference draws with noise_like, lvdm/common.py:31-34)."""
         if ddim_use_original_steps or timesteps is not None:
             raise NotImplementedError("only the DDIM sub-schedule is supported (ddim_use_original_steps=False)")
-        if mask is not None:
-            raise NotImplementedError("mask/x0 blending is not on the generation path of 02_generate_videos.py")
-        for flag in ("paste_overlap_frames", "noise_shaping"):
-            if kwargs.get(flag):
-                raise NotImplementedError(f"{flag} belongs to the autoregressive demo path, not to the hot path")
+        if mask is not None and x0 is None:
+            raise ValueError("mask needs x0 (ddim.py:175)")
+        # latent edits in front of / inside a step (ddim.py:174-199, 316-326): mask / x0 blending, pasted overlap frames of the
+        # autoregressive loop, scene-constrained noise shaping, v / dynamically rescaled schedules -- none is on the path of
+        # 02_generate_videos.py; they take the sampler's general (torch) step, eager
+        n_overlap = int(kwargs.get("num_overlap", 0)) if kwargs.get("paste_overlap_frames") else 0
+        shaping = bool(kwargs.get("noise_shaping"))
+        side = (mask is not None or n_overlap > 0 or shaping or bool(kwargs.get("paste_cond_frame"))
+                or getattr(self.model, "parameterization", "eps") != "eps" or getattr(self.model, "use_dynamic_rescale", False))
         device = self.model.betas.device
         b = shape[0]
         img = _shared_draw(self.model, rng.randn(shape, device=device)) if x_T is None else x_T.to(device).float().contiguous()
         steps = self.ddim_timesteps
         total = steps.shape[0]
         intermediates = {"x_inter": [img], "pred_x0": [img]}
-        kwargs.pop("clean_cond", None)
+        clean_cond = kwargs.pop("clean_cond", False)
         # every timestep tensor is built up front: no host->device traffic inside the loop
         ts_all = torch.from_numpy(np.ascontiguousarray(np.flip(steps))).to(device=device, dtype=torch.long)
         ts_all = ts_all[:, None].expand(total, b).contiguous()
@@ -401,12 +417,23 @@ class DDIMSampler(object):
                        unconditional_conditioning=unconditional_conditioning, fs=fs, guidance_rescale=guidance_rescale,
                        **kwargs)
         graphed = None
-        if use_graph and not (callback or img_callback):
+        if use_graph and not (callback or img_callback) and not side:
             stochastic = bool(np.any(self.ddim_sigmas != 0.0))
             graphed = _GraphedClip.get(self, img, cond, stochastic, step_kw)
         for i in range(total):
             index = total - i - 1
             z = injected_noise[i].to(device).float().contiguous() if injected_noise is not None else None
+            if mask is not None:           # keep the (noised) original where the mask is set (ddim.py:174-181)
+                img_orig = x0 if clean_cond else self.model.q_sample(x0, ts_all[i])
+                img = img_orig * mask + (1.0 - mask) * img
+            if n_overlap > 0:              # the overlap frames follow the noised previous clip (ddim.py:183-189)
+                img = img.clone()
+                img[:, :, :n_overlap] = self.model.q_sample(cond["origin_z_0"][:, :, :n_overlap], ts_all[i])
+            if shaping and int(ts_all[i][0]) >= kwargs["noise_shaping_minimum_timesteps"]:      # ddim.py:191-201
+                src = kwargs["scene_frames"] if "scene_frames" in kwargs else cond["origin_z_0"]
+                img_orig = self.model.q_sample(src, ts_all[i])
+                scene_mask = kwargs["scene_mask"]
+                img = img_orig * scene_mask + (1.0 - scene_mask) * img
             if graphed is not None:
                 img, pred_x0 = graphed.run(img, ts_all[i], self.ddim_coef[index], z)
                 if index % log_every_t == 0 or index == total - 1:
@@ -428,6 +455,9 @@ class DDIMSampler(object):
                 intermediates["pred_x0"].append(pred_x0)
         if graphed is not None:
             img = img.clone()  # detach the result from the graph's static output buffer
+        if n_overlap > 0:                  # ddim.py:228-231
+            img = img.clone()
+            img[:, :, :n_overlap] = cond["origin_z_0"][:, :, :n_overlap]
         if kwargs.get("paste_cond_frame"):
             idx = cond["c_cond_frame_index"]
             bi = torch.arange(img.shape[0], device=device)
@@ -491,10 +521,14 @@ class DDIMSampler(object):
         ``index`` (lets a captured hipGraph be replayed for every step)."""
         if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.0:
             raise NotImplementedError("original-step / quantised / corrected / dropout sampling is not on the hot path")
-        if getattr(self.model, "parameterization", "eps") != "eps":
-            raise NotImplementedError("only the eps parameterisation is used by the shipped configs")
         x = x.float().contiguous()
         e_c, e_uc = self._predict_noise(x, c, t, unconditional_guidance_scale, unconditional_conditioning, kwargs)
+        n_overlap = int(kwargs.get("num_overlap", 0)) if kwargs.get("paste_overlap_frames") else 0
+        v_param = getattr(self.model, "parameterization", "eps") == "v"
+        dyn = getattr(self.model, "use_dynamic_rescale", False)
+        if v_param or dyn or n_overlap > 0 or kwargs.get("paste_cond_frame"):
+            return self._general_step(x, c, t, index, e_c, e_uc, unconditional_guidance_scale, guidance_rescale, noise, coef, temperature,
+                                      repeat_noise, v_param, dyn, n_overlap, bool(kwargs.get("paste_cond_frame")))
         if noise is None and coef is None and float(self.ddim_sigmas[index]) != 0.0:
             shape = (1, *x.shape[1:]) if repeat_noise else x.shape
             noise = _shared_draw(self.model, rng.randn(shape, device=x.device).expand(x.shape).contiguous())
@@ -503,9 +537,45 @@ class DDIMSampler(object):
         x_prev, pred_x0 = ops.ddim_cfg_step(x, e_c.float().contiguous(), None if e_uc is None else e_uc.float().contiguous(),
                                             noise, coef if coef is not None else self.ddim_coef[index],
                                             unconditional_guidance_scale, guidance_rescale)
-        if kwargs.get("paste_cond_frame"):
-            raise NotImplementedError("paste_cond_frame inside the step is not on the generation path")
+        return x_prev, pred_x0
+
+    def _general_step(self, x, c, t, index, e_c, e_uc, scale, guidance_rescale, noise, coef, temperature, repeat_noise, v_param, dyn,
+                      n_overlap, paste_cond):
+        """The step of ddim.py:266-346 in plain fp32 tensor arithmetic, for the branches the fused kernel does not cover: v
+        parameterisation, dynamic rescale of the predicted x0, frames pasted into the predicted x0 (``paste_cond_frame``,
+        ``paste_overlap_frames``).  Guidance, the camera term (already folded into e_uc by ``_predict_noise``) and the std rescale as
+        in the reference (utils_diffusion.py:147-157)."""
+        e_c = e_c.float()
+        out = e_c if e_uc is None else e_uc.float() + scale * (e_c - e_uc.float())
+        if e_uc is not None and guidance_rescale > 0.0:
+            dims = list(range(1, out.dim()))
+            rescaled = out * (e_c.std(dim=dims, keepdim=True) / out.std(dim=dims, keepdim=True))
+            out = guidance_rescale * rescaled + (1.0 - guidance_rescale) * out
+        row = coef if coef is not None else self.ddim_coef[index]
+        a_t, a_prev, sigma_t, sqrt_one_minus_at = row[0], row[1], row[2], row[3]
+        if v_param:
+            e_t = self.model.predict_eps_from_z_and_v(x, t, out)
+            pred_x0 = self.model.predict_start_from_z_and_v(x, t, out)
+        else:
+            e_t = out
+            pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+        if dyn:
+            pred_x0 = pred_x0 * (self.ddim_scale_arr_prev[index] / self.ddim_scale_arr[index]).to(pred_x0)
+        if paste_cond:
+            bi = torch.arange(pred_x0.shape[0], device=x.device)
+            pred_x0 = pred_x0.clone()
+            pred_x0[bi, :, c["c_cond_frame_index"]] = c["origin_z_0"][bi, :, c["c_cond_frame_index"]].to(pred_x0)
+        if n_overlap > 0:
+            pred_x0 = pred_x0.clone()
+            pred_x0[:, :, :n_overlap] = c["origin_z_0"][:, :, :n_overlap].to(pred_x0)
+        dir_xt = (1.0 - a_prev - sigma_t ** 2).clamp(min=0).sqrt() * e_t
+        if noise is None and float(sigma_t) != 0.0:
+            shape = (1, *x.shape[1:]) if repeat_noise else x.shape
+            noise = _shared_draw(self.model, rng.randn(shape, device=x.device).expand(x.shape).contiguous())
+        x_prev = a_prev.sqrt() * pred_x0 + dir_xt
+        if noise is not None:
+            x_prev = x_prev + sigma_t * noise * temperature
         return x_prev, pred_x0
 
 
-__all__ = ["DDIMSampler", "make_beta_schedule", "make_ddim_timesteps", "make_ddim_sampling_parameters", "CcvError"]
+__all__ = ["DDIMSampler", "make_beta_schedule", "make_ddim_timesteps", "make_ddim_sampling_parameters", "rescale_zero_terminal_snr", "CcvError"]

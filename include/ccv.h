@@ -238,7 +238,7 @@ typedef struct CcvAttn {
                               * 64-query groups whose K / V blocks one workgroup stages once: 4 for its 8-wave form, 2 for the
                               * 4-wave form) by decreasing size of the union of their needed key blocks.  NULL or another
                               * wg_merge than the kernel's: items are handed out in index order (same result, longer tail). */
-    void* split_ws; int64_t split_ws_bytes; /* NULL or >= ccv_attn_split_ws_bytes(p) bytes whose first bytes (the counters: the whole
+    void* split_ws; int64_t split_ws_bytes; /* NULL or >= ccv_attn_split_ws_bytes(p) bytes whose first 64 KiB (the counters: the whole
                               * buffer may simply be zeroed) the caller ZEROED once before its first use on `stream`: workspace of the
                               * workgroup-shared sparse kernel's key-split items (the shortest items come in 2-4 parts so that the
                               * persistent workgroups finish together; the part that finishes last merges them and resets its counter, so

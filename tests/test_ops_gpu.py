@@ -539,6 +539,7 @@ def test_attention_shared_kv_kernel(ops, L, H, density, perm):
 
 @pytest.mark.parametrize("T,hl,H,B,split_all", [(16, 16, 5, 2, 4),      # 640 items over 1024 workgroup slots: on request every item in 3 parts
                                                 (16, 32, 5, 2, 0),      # 1280 items: the 260 shortest in 2 parts (the default rule)
+                                                (32, 32, 5, 2, 0),      # a 32-frame clip: 2560 items of up to 1025 steps, 1540 of them in 2 parts
                                                 (12, 16, 3, 1, 4)])     # 72 items: on request 4 parts
 def test_attention_shared_kernel_key_split_items(ops, T, hl, H, B, split_all):
     """Key-split items of the workgroup-shared sparse kernel (the queue's tail in 2-4 parts, merged by the part that finishes last):
@@ -583,11 +584,11 @@ def test_attention_shared_kernel_key_split_items(ops, T, hl, H, B, split_all):
     torch.cuda.synchronize()
     ws = ops._SPLIT_WS[key]
     assert int(ws[:256].view(torch.int32).abs().sum()) == 0, "the merging parts must leave the counters at zero"      # (>= 64 counters in every case here)
-    # a call of another size reuses (or grows) the same workspace; then this one again: unchanged
-    small = dict(kw, B=1)
-    ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **small)
-    again = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **kw)
-    assert torch.equal(again, outs[0])
+    # calls of other sizes (fewer / more split items: as the layers of one forward alternate) share the workspace; then this one again
+    for other in (dict(kw, B=1), dict(kw, H=H - 1), dict(kw, B=1, H=2, split_all=3)):
+        ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **other)
+        again = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], **kw)
+        assert torch.equal(again, outs[0]), f"result changed after a call with {other.get('B')}, {other.get('H')} sharing the workspace"
 
 
 @pytest.mark.parametrize("fh,fw", [(8, 16), (12, 24)])

@@ -381,3 +381,14 @@ def test_per_op_oracle_vs_reference_module_fixtures(golden_dir):
         err = ((a - b).norm() / b.norm()).item()
         assert err <= 2e-5, f"{k}: rel-L2 {err:.3e}"
         _close(a, b)
+
+
+def test_zero_terminal_snr_betas_vs_reference(golden_dir):
+    """rescale_betas_zero_snr (lvdm/models/utils_diffusion.py:112-144): the product's restatement against the reference's betas."""
+    from camc2v_amd.sampler import rescale_zero_terminal_snr
+    from oracle import sampler_cases
+    fx = np.load(os.path.join(golden_dir, "ddim_branches.npz"))
+    got = rescale_zero_terminal_snr(sampler_cases.schedule())
+    assert np.allclose(got, fx["betas_zero_snr"], rtol=1e-12, atol=1e-15)
+    assert np.allclose(got, 1.0 - (1.0 - sampler_cases.schedule(zero_snr=True)), rtol=1e-12, atol=1e-15)
+    assert abs(np.cumprod(1.0 - got)[-1]) < 1e-12                  # zero terminal SNR
