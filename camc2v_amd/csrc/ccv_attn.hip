@@ -1382,44 +1382,53 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
         const unsigned ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)item_word[2]);
         if (ticket != (unsigned)(nparts - 1)) continue;                          // somebody else will merge
         if (tid == 0) p.split_ctr[sidx] = 0u;                                    // for the next launch that uses this workspace
-        // merge in part order (own part from registers): the same arithmetic whoever arrived last
-        float M = NEG_INF, Ls = 0.f;
-        f32x16 om[2];
+        // merge (own part from registers): O = sum over the parts IN PART ORDER of O_q 2^(m_q - max_q m_q), products and sums not contracted:
+        // the same arithmetic whoever arrived last.  Two passes so that at most 16 + 16 values are live beside the accumulators.
+        float mqs[4], lqs[4], M = NEG_INF;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) om[d][e] = 0.f;
-        for (int q = 0; q < nparts; ++q) {
-            float mq, lq;
-            const float4* src = area(q);
-            f32x4 got[9];                                                      // the other part's lane slot: nine 16-byte sc1 loads, one wait
-            if (q != part) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(got[c]) : "v"(src + c * 64) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(got[0]), "+v"(got[1]), "+v"(got[2]), "+v"(got[3]), "+v"(got[4]), "+v"(got[5]), "+v"(got[6]),
-                             "+v"(got[7]), "+v"(got[8])::"memory");
+        for (int q = 0; q < 4; ++q) {
+            mqs[q] = NEG_INF; lqs[q] = 0.f;
+            if (q < nparts) {
+                if (q == part) { mqs[q] = m_run; lqs[q] = l_run; }
+                else {
+                    f32x4 tl;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(tl) : "v"(area(q) + 8 * 64) : "memory");
+                    lqs[q] = tl[0]; mqs[q] = tl[1];
+                }
+                M = fmaxf(M, mqs[q]);
             }
-            if (q == part) { mq = m_run; lq = l_run; }
-            else { lq = got[8][0]; mq = got[8][1]; }
-            const float mn = fmaxf(M, mq);
-            const float mu = (mn == NEG_INF) ? 0.f : mn;
-            const float a = __builtin_amdgcn_exp2f(M - mu), bq = __builtin_amdgcn_exp2f(mq - mu);
-            Ls = __fadd_rn(__fmul_rn(Ls, a), __fmul_rn(lq, bq));
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                f32x4 t;
-                if (q == part) { t[0] = oacc[c >> 2][4 * (c & 3)]; t[1] = oacc[c >> 2][4 * (c & 3) + 1]; t[2] = oacc[c >> 2][4 * (c & 3) + 2]; t[3] = oacc[c >> 2][4 * (c & 3) + 3]; }
-                else t = got[c];
-                const int d_ = c >> 2, e_ = 4 * (c & 3);
-                om[d_][e_] = __fadd_rn(__fmul_rn(om[d_][e_], a), __fmul_rn(t[0], bq));
-                om[d_][e_ + 1] = __fadd_rn(__fmul_rn(om[d_][e_ + 1], a), __fmul_rn(t[1], bq));
-                om[d_][e_ + 2] = __fadd_rn(__fmul_rn(om[d_][e_ + 2], a), __fmul_rn(t[2], bq));
-                om[d_][e_ + 3] = __fadd_rn(__fmul_rn(om[d_][e_ + 3], a), __fmul_rn(t[3], bq));
-            }
-            M = mn;
         }
-        oacc[0] = om[0];
-        oacc[1] = om[1];
+        const float mu = (M == NEG_INF) ? 0.f : M;
+        float wq[4], Ls = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wq[q] = __builtin_amdgcn_exp2f(mqs[q] - mu);
+            if (q < nparts) Ls = __fadd_rn(Ls, __fmul_rn(lqs[q], wq[q]));
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 sum;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+            for (int q = 0; q < nparts; ++q) {
+                f32x4 t[4];
+                if (q == part) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { t[c][0] = oacc[half][4 * c]; t[c][1] = oacc[half][4 * c + 1]; t[c][2] = oacc[half][4 * c + 2]; t[c][3] = oacc[half][4 * c + 3]; }
+                } else {
+                    const float4* src = area(q) + (4 * half) * 64;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[c]) : "v"(src + c * 64) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
+                }
+                const float w = q == 0 ? wq[0] : (q == 1 ? wq[1] : (q == 2 ? wq[2] : wq[3]));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum[4 * c + e] = __fadd_rn(sum[4 * c + e], __fmul_rn(t[c][e], w));
+            }
+            oacc[half] = sum;
+        }
         l_run = Ls;
     }
     {
