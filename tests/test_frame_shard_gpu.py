@@ -169,7 +169,7 @@ def test_frame_sharded_forward_equals_unsharded(world, golden_dir, tmp_path):
             if name.startswith("vs reference"):
                 tol = (2.5e-2, 5e-2)          # the fixture bound of the unsharded path (test_medium_fixture_tight_tolerance)
             elif name.startswith("25-step"):
-                tol = (5e-2, 1.0)             # TOL_CAM of tests/test_trajectory_gpu.py (unsharded: 3.3e-2)
+                tol = (4.2e-2, 1.0)           # TOL_CAM of tests/test_trajectory_gpu.py (unsharded: 3.4e-2)
             elif name.startswith("layer:"):
                 tol = (1e-3, 1e-2)            # exchanges, halos, frame offsets, local mask rows (only GEMM tile choices differ)
             else:
@@ -239,7 +239,7 @@ def _cfg_split_worker(rank, world, port, golden_dir, out_dir):
 def test_cfg_split_over_two_ranks(golden_dir, tmp_path):
     """SURVEY.md section 8e "CFG split": rank 0 runs the conditional forward of every step, rank 1 the unconditional one, one all_gather
     of the noise prediction per step (parallel.CfgSplit).  The 25-step CFG-7.5 trajectory of the reference's own sampler (fixture of
-    tests/test_trajectory_gpu.py) must be met within that test's tolerance (5e-2; unsplit 3.3e-2) by the eager and by the graph form
+    tests/test_trajectory_gpu.py) must be met within that test's tolerance (4.2e-2; unsplit 3.4e-2) by the eager and by the graph form
     (each rank's forward a hipGraph, exchange + update after every replay), which must agree bit for bit; both ranks end with the
     same latents; against the unsplit sampler (one 2b-batch forward instead of two b-batch ones, i.e. other GEMM tiles: another
     rounding realisation, each 3.3e-2 from the reference after 25 steps) within 6e-2 (measured 4.0e-2)."""
@@ -250,5 +250,5 @@ def test_cfg_split_over_two_ranks(golden_dir, tmp_path):
         res = json.load(open(tmp_path / f"rank{r}.json"))
         print(f"[parity] CFG split, rank {r}: {res}")
         assert res["graph equals eager"] and res["ranks agree"] == 0.0
-        assert res["trajectory vs REFERENCE"] <= 5e-2
+        assert res["trajectory vs REFERENCE"] <= 4.2e-2
         assert res["vs unsplit (one 2b forward)"] <= 6e-2

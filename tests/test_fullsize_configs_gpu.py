@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-REL_L2, MAX_REL = 2.5e-2, 8e-2
+REL_L2, MAX_REL = 2.0e-2, 4e-2
 
 
 class _workload:

@@ -4,7 +4,7 @@ configs[1]: 1.5 B-parameter CamContextI2V UNet, 1 x 16 x 256 x 256 clip, camera 
   * one CFG step's UNet work -- the conditional half (context 77 + 768 tokens) and the unconditional half (77 + 256),
     both camera conditioned (Pluecker rows, register tokens, the 16384 / 4096 / 1024 / 256-token epipolar masks) -- run
     as the product runs it (`apply_model_pair`, native packed masks) against `oracle.unet_oracle.unet_forward` on the
-    host with the same weights, inputs and fundamental matrices.  Stated tolerance: rel-L2 <= 2.5e-2 per half.
+    host with the same weights, inputs and fundamental matrices.  Stated tolerance: rel-L2 <= 2.0e-2 per half (measured 1.55 ... 1.60e-2).
   * the HIP epipolar-mask kernel at the headline size (32x32 latents, L = 16384) against the per-query-row popcounts
     the REFERENCE produced for the same F (tests/golden/geometry.npz, written by oracle/gen_golden.py).
 """
@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-REL_L2, MAX_REL = 2.5e-2, 8e-2
-TRAJ_REL_L2 = 5e-2        # x_t after each of the first three steps of the 25-step schedule (eta = 1, injected noise): the stated trajectory
+REL_L2, MAX_REL = 2.0e-2, 4e-2       # round 4: tightened to 1.25x / 1.6x the measured 1.60e-2 / 2.5e-2 (were 2.5e-2 / 8e-2)
+TRAJ_REL_L2 = 4e-2          # x_t after each of the first three steps of the 25-step schedule (eta = 1, injected noise): the stated trajectory
                           # tolerance of tests/test_trajectory_gpu.py (guidance 7.5 amplifies the per-forward error of 1.6e-2); measured 2.0e-2 / 2.5e-2 / ...
 
 
@@ -97,7 +97,7 @@ def test_full_size_three_step_trajectory_vs_ddim_oracle(full):
     """The first three steps (t = 999, 959, 919) of the headline 25-step schedule -- CFG 7.5, guidance_rescale 0.7, eta = 1 with the
     N(0,1) draws injected -- through the product's sampler (`DDIMSampler.p_sample_ddim`: batched cond+uncond forward, fused
     guidance + rescale + update) against `oracle.ddim_oracle.cfg_ddim_update` around oracle forwards, each side evolving its own
-    latents.  Stated tolerance: rel-L2 of x_t <= 5e-2 after every step (as for the 25-step medium trajectory); the noise predictions of the first step (t = 999, the
+    latents.  Stated tolerance: rel-L2 of x_t <= 4e-2 after every step (measured 2.0e-2, 2.5e-2, ...); the noise predictions of the first step (t = 999, the
     step where |eps| and the timestep embedding are largest) are held to the single-step tolerance."""
     from camc2v_amd.sampler import DDIMSampler
     from oracle import ddim_oracle

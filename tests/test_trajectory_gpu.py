@@ -4,8 +4,8 @@ medium-width network -- model_channels 128, 16 frames of 16x16 latents -- with t
 02_generate_videos.py:318-327; the sampler's N(0,1) draws are reproduced from the recorded seed and injected).
 
 Stated tolerance over 25 steps (bf16 GEMM/attention operands against the reference's fp32):
-    camera-conditioned, CFG 7.5, guidance_rescale 0.7, eta 1:  rel-L2 of x_t <= 5e-2 at every recorded step   (measured 2.0e-2 after step 1 ... 3.3e-2 from step 10 on)
-    DynamiCrafter (no camera), CFG off, eta 1:                 rel-L2 of x_t <= 1.5e-2 at every recorded step (measured 3.4e-3 ... 5.0e-3)
+    camera-conditioned, CFG 7.5, guidance_rescale 0.7, eta 1:  rel-L2 of x_t <= 4.2e-2 at every recorded step  (measured 2.0e-2 after step 1 ... 3.4e-2 from step 10 on)
+    DynamiCrafter (no camera), CFG off, eta 1:                 rel-L2 of x_t <= 8e-3 at every recorded step   (measured 3.4e-3 ... 5.0e-3)
 (single forward: 2e-2, tests/test_unet_gpu.py::test_medium_fixture_tight_tolerance).  The per-step errors are printed:
 they do not grow with the step count -- the DDIM update contracts the error as the noise level falls.
 """
@@ -19,7 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TOL_CAM, TOL_DC = 5e-2, 1.5e-2
+TOL_CAM, TOL_DC = 4.2e-2, 8e-3       # round 4: tightened to 1.25x / 1.6x the measured 3.36e-2 / 5.0e-3 (were 5e-2 / 1.5e-2); the fp16-operand build is held to 1e-2
 
 
 def _noises(seed, sums, shape):
