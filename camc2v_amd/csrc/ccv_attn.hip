@@ -385,23 +385,28 @@ __device__ __forceinline__ void attn_block_coords(int nq, int H, int& qblk, int&
 // of its own follows the first in the same tile sequence: when the first tile of the second context comes up, the
 // normalised result of the first is parked as packed bf16 (32 registers) and the running max / sum / accumulators start
 // over; the epilogue writes o1 + gate2 * o2.  Unmasked calls only.
-template <bool MASKED, bool TWO = false>
-__global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
+// NQB = 32-query blocks per wave: 2 (64 queries per wave, 256 per workgroup, two workgroups per CU) or -- round 4 -- 1 (32 queries per wave,
+// 128 per workgroup: half the accumulators, four workgroups = 16 waves per CU, so that one wave's softmax runs under three others' MFMAs and
+// LDS reads; the same arithmetic per query, bit-identical results).
+template <bool MASKED, bool TWO = false, int NQB = 2>
+__global__ __launch_bounds__(256, NQB == 1 ? 4 : 2) void attn2_kernel(const CcvAttn p) {
+    static_assert(NQB == 1 || NQB == 2, "one or two 32-query blocks per wave");
+    constexpr int QW = 128 * NQB;        // queries per workgroup
     static_assert(!(MASKED && TWO), "the two-context form has no mask path");
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar for the compiler (M0 of the K/V DMA)
     const int r = lane & 31, hh = lane >> 5;
     int qblk, head, b;
-    attn_block_coords((p.Lq + 255) / 256, p.H, qblk, head, b);
+    attn_block_coords((p.Lq + QW - 1) / QW, p.H, qblk, head, b);
     const long bo = b / p.inner, bi = b % p.inner;
-    const int q0 = qblk * 256 + wave * 64;
+    const int q0 = qblk * QW + wave * (32 * NQB);
     const bool wave_active = q0 < p.Lq;
 
-    bf16x8 qf[2][4];
-    int qi[2];
+    bf16x8 qf[NQB][4];
+    int qi[NQB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         qi[qb] = min(q0 + 32 * qb + r, p.Lq - 1);   // index in mask / schedule order
         const uint16_t* qp = p.q + bo * p.q_bso + bi * p.q_bsi + (long)ccv_patch_row(qi[qb], p.perm_hw, p.perm_w) * p.q_ls + head * 64 + 8 * hh;
 #pragma unroll
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     const int n_total = n_first + (TWO ? (p.Lk2 + KT - 1) / KT : 0);
     constexpr bool masked = MASKED;
     const uint8_t* flags = (masked && p.tile_flags) ? p.tile_flags + (long)(b % p.mask_nb) * p.flags_bs : nullptr;
-    const int fq0 = 2 * qblk, fq1 = min(2 * qblk + 1, (p.Lq + 127) / 128 - 1);
+    const int fq0 = NQB * qblk, fq1 = min(NQB * qblk + NQB - 1, (p.Lq + 127) / 128 - 1);     // the flag rows (128 queries each) of this workgroup
 
     auto next_tile = [&](int it) {  // first schedulable tile index >= it (block-uniform)
         while (it < n_total) {
@@ -474,21 +479,23 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         }
     };
 
-    float m_run[2] = {NEG_INF, NEG_INF}, l_run[2] = {0.f, 0.f};
-    f32x16 oacc[2][2];
+    float m_run[NQB], l_run[NQB];
+    f32x16 oacc[NQB][2];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = NEG_INF; l_run[qb] = 0.f; }
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
 
-    uint32_t o1pk[TWO ? 2 : 1][2][8];   // first context's normalised output, packed bf16 pairs
+    uint32_t o1pk[TWO ? NQB : 1][2][8];   // first context's normalised output, packed bf16 pairs
     // mask words of a tile: [query block][32-key block]; loaded one tile ahead so their latency hides behind
     // the current tile's math (register tokens and unmasked calls see all-ones)
-    auto load_words = [&](int it, uint32_t (&w)[2][2]) {
+    auto load_words = [&](int it, uint32_t (&w)[NQB][2]) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 w[qb][kb] = 0xffffffffu;
@@ -503,12 +510,12 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
     // retire the Q-fragment loads where hipcc can see it (see attn_sparse_kernel): otherwise every use of qf in the
     // loop is preceded by s_waitcnt vmcnt(0), which waits for the NEXT tile's DMA and serialises the ring
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) asm volatile("" ::"v"(qf[qb][s4]));
 
     int cur = next_tile(0), stage = 0;
-    uint32_t mwc[2][2], mwn[2][2];
+    uint32_t mwc[NQB][2], mwn[NQB][2];
     if (cur < n_total) issue(cur, 0);
     load_words(cur, mwc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
 
         if (TWO && cur == n_first) {   // block-uniform: park the first softmax's result, start the second
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
                 const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
 #pragma unroll
@@ -542,11 +549,11 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
             const int nvalid = min(KT, (is_reg ? p.nreg : (second ? p.Lk2 : p.Lk)) - k0);
             const unsigned char* sK = sm + stage * (2 * KT * 128);
             const unsigned char* sV = sK + KT * 128;
-            uint32_t mw[2][2];
-            bool on[2][2];
+            uint32_t mw[NQB][2];
+            bool on[NQB][2];
             bool any_on = false;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     uint32_t w = mwc[qb][kb];
@@ -562,34 +569,29 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                 // every K / V^T fragment read from LDS feeds both query blocks
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const bool on0 = on[0][kb], on1 = on[1][kb];
-                    if (!(on0 || on1)) continue;
-                    f32x16 sa0 = zero16, sa1 = zero16;
+                    bool any_q = false;
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb) any_q |= on[qb][kb];
+                    if (!any_q) continue;
+                    f32x16 sa[NQB];
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb) sa[qb] = zero16;
                     const int krow = 32 * kb + r;
-                    if (!MASKED || (on0 && on1)) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const int c = 2 * s + hh;
-                            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
-                            sa0 = ccv_mfma_32x32x16(kf, qf[0][s], sa0);
-                            sa1 = ccv_mfma_32x32x16(kf, qf[1][s], sa1);
-                        }
-                    } else {
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = 2 * s + hh;
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const int c = 2 * s + hh;
-                            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((c ^ ((krow >> 1) & 7)) << 4));
-                            if (on0) sa0 = ccv_mfma_32x32x16(kf, qf[0][s], sa0);
-                            else     sa1 = ccv_mfma_32x32x16(kf, qf[1][s], sa1);
-                        }
+                        for (int qb = 0; qb < NQB; ++qb)
+                            if (!MASKED || on[qb][kb]) sa[qb] = ccv_mfma_32x32x16(kf, qf[qb][s], sa[qb]);
                     }
-                    bf16x8 pf0[2], pf1[2];
-                    auto softmax_block = [&](f32x16& sa, uint32_t w, float& m_r, float& l_r, f32x16 (&oa)[2], bf16x8 (&pfo)[2]) {
-                        const bool all_visible = __builtin_amdgcn_readfirstlane((int)__all(w == 0xffffffffu)) != 0;
-                        softmax_block32(sa, w, all_visible, hh, sl2, m_r, l_r, oa, pfo);
-                    };
-                    if (!MASKED || on0) softmax_block(sa0, mw[0][kb], m_run[0], l_run[0], oacc[0], pf0);
-                    if (!MASKED || on1) softmax_block(sa1, mw[1][kb], m_run[1], l_run[1], oacc[1], pf1);
+                    bf16x8 pf[NQB][2];
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb)
+                        if (!MASKED || on[qb][kb]) {
+                            const bool all_visible = __builtin_amdgcn_readfirstlane((int)__all(mw[qb][kb] == 0xffffffffu)) != 0;
+                            softmax_block32(sa[qb], mw[qb][kb], all_visible, hh, sl2, m_run[qb], l_run[qb], oacc[qb], pf[qb]);
+                        }
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         const int kb0 = 32 * kb + 16 * s2 + 4 * hh;
@@ -605,8 +607,9 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
                             bf16x8 vf;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                            if (!MASKED || on0) oacc[0][d] = ccv_mfma_32x32x16(vf, pf0[s2], oacc[0][d]);
-                            if (!MASKED || on1) oacc[1][d] = ccv_mfma_32x32x16(vf, pf1[s2], oacc[1][d]);
+#pragma unroll
+                            for (int qb = 0; qb < NQB; ++qb)
+                                if (!MASKED || on[qb][kb]) oacc[qb][d] = ccv_mfma_32x32x16(vf, pf[qb][s2], oacc[qb][d]);
                         }
                     }
                 }
@@ -617,13 +620,13 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const CcvAttn p) {
         cur = nxt;
         stage ^= 1;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) mwc[qb][kb] = mwn[qb][kb];
     }
 
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float wgt = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         const int q = q0 + 32 * qb + r;
@@ -1565,7 +1568,7 @@ static long sparse_pct() {   // persistent workgroups in percent of the CU count
 }
 static bool takes_sparse_path(const CcvAttn& p) {
     return (p.variant == 0 || p.variant >= 3) && p.k2 == nullptr && p.mask_bits && p.wave_bits &&
-           (p.variant >= 3 || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024);
+           ((p.variant >= 3 && p.variant <= 6) || (long)((p.Lq + 63) / 64) * p.H * p.B >= 1024);
 }
 // waves per workgroup of the workgroup-shared kernel for this call, 0 = the per-wave kernel.  variant 4 / 5 force the 8- / 4-wave form,
 // variant 6 the per-wave kernel; otherwise CCV_ATTN_SHARED = 4 (default: measured fastest, profiles/r04_sparse_shared_kv.txt) | 8 | 0
@@ -1629,6 +1632,13 @@ extern "C" int64_t ccv_attn_split_ws_bytes(const CcvAttn* pp) {
     return split_plan(*pp, nw).total_bytes;
 }
 
+// CCV_ATTN2_Q32: bit mask of the tiled-attention forms that run with 32 queries per wave (attn2_kernel<.., .., 1>: four workgroups per CU)
+// instead of 64: 1 = two-context cross attention, 2 = unmasked single context, 4 = masked tiled (A/B aid; default below)
+static int attn2_q32(const CcvAttn& p) {
+    static const int v = [] { const char* e = getenv("CCV_ATTN2_Q32"); return e ? atoi(e) & 7 : 0; }();
+    return p.variant == 7 ? 7 : v;      // variant 7: as 0, every tiled form with 32 queries per wave (tests)
+}
+
 static bool two_ctx_on() {   // CCV_ATTN_TWO=0: two-context calls on the first-generation kernel (A/B aid)
     static const bool v = [] { const char* e = getenv("CCV_ATTN_TWO"); return !(e && e[0] == '0'); }();
     return v;
@@ -1642,7 +1652,7 @@ static CcvAttn fold_shared_kv(const CcvAttn& in) {
     static const bool on = [] { const char* e = getenv("CCV_ATTN_FOLD"); return !(e && e[0] == '0'); }();
     CcvAttn p = in;
     const bool shared = p.k_bsi == 0 && p.v_bsi == 0 && (!p.k2 || (p.k2_bsi == 0 && p.v2_bsi == 0));
-    if (on && shared && p.inner > 1 && p.B % p.inner == 0 && !p.mask_bits && !p.kreg && p.perm_w == 0 && p.variant == 0 &&
+    if (on && shared && p.inner > 1 && p.B % p.inner == 0 && !p.mask_bits && !p.kreg && p.perm_w == 0 && (p.variant == 0 || p.variant == 7) &&
         p.q_bsi == (int64_t)p.Lq * p.q_ls && p.o_bsi == (int64_t)p.Lq * p.o_ls && (long)p.inner * p.Lq < (1l << 30) && p.Lq > 16) {
         p.Lq *= p.inner;
         p.B /= p.inner;
@@ -1667,7 +1677,7 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(!p.mask_bits || p.mask_nb > 0, CCV_EINVAL, "ccv_attn_fwd: mask_nb must be positive");
     CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
     CCV_REQUIRE(!(p.variant >= 3 && p.variant <= 6) || (p.wave_bits && !p.k2), CCV_EINVAL, "ccv_attn_fwd: variants 3-6 need wave_bits and a single context");
-    CCV_REQUIRE(p.variant >= 0 && p.variant <= 6, CCV_EINVAL, "ccv_attn_fwd: unknown variant %d", p.variant);
+    CCV_REQUIRE(p.variant >= 0 && p.variant <= 7, CCV_EINVAL, "ccv_attn_fwd: unknown variant %d", p.variant);
     CCV_REQUIRE(!p.wave_bits || (p.mask_bits && (long)p.wave_words * 32 * 32 >= p.Lk), CCV_EINVAL,
                 "ccv_attn_fwd: wave_bits needs mask_bits and wave_words covering Lk");
     CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
@@ -1688,6 +1698,9 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
         const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
         CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
         dim3 grid2((unsigned)nwg2);
+        const long nwg2h = (long)((p.Lq + 127) / 128) * p.H * p.B;      // 32 queries per wave (attn2_kernel<.., .., 1>)
+        CCV_REQUIRE(nwg2h < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
+        dim3 grid2h((unsigned)nwg2h);
         if (takes_sparse_path(p)) {
             // persistent: 2 workgroups per CU (LDS-bound), fewer when there are fewer 64-query groups than waves
             static std::atomic<int> next_slot{0};
@@ -1756,13 +1769,21 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             } else
             hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
         }
-        else if (p.mask_bits)
-            hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
-        else
-            hipLaunchKernelGGL(attn2_kernel<false>, grid2, dim3(256), 0, st, p);
-    } else if (p.variant == 0 && p.k2 && !p.mask_bits && p.perm_w == 0 && two_ctx_on()) {   // two contexts (text + gated image tokens)
+        else if (p.mask_bits) {
+            if (attn2_q32(p) & 4) hipLaunchKernelGGL((attn2_kernel<true, false, 1>), grid2h, dim3(256), 0, st, p);
+            else                 hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
+        } else {
+            if (attn2_q32(p) & 2) hipLaunchKernelGGL((attn2_kernel<false, false, 1>), grid2h, dim3(256), 0, st, p);
+            else                 hipLaunchKernelGGL(attn2_kernel<false>, grid2, dim3(256), 0, st, p);
+        }
+    } else if ((p.variant == 0 || p.variant == 7) && p.k2 && !p.mask_bits && p.perm_w == 0 && two_ctx_on()) {   // two contexts (text + gated image tokens)
         const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
         CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
+        if (attn2_q32(p) & 1) {
+            const long nwg2h = (long)((p.Lq + 127) / 128) * p.H * p.B;
+            CCV_REQUIRE(nwg2h < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
+            hipLaunchKernelGGL((attn2_kernel<false, true, 1>), dim3((unsigned)nwg2h), dim3(256), 0, st, p);
+        } else
         hipLaunchKernelGGL((attn2_kernel<false, true>), dim3((unsigned)nwg2), dim3(256), 0, st, p);
     } else if (p.variant == 0 || p.variant == 1)
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, p);
