@@ -391,6 +391,8 @@ __device__ __forceinline__ void attn_block_coords(int nq, int H, int& qblk, int&
 template <bool MASKED, bool TWO = false, int NQB = 2>
 __global__ __launch_bounds__(256, NQB == 1 ? 4 : 2) void attn2_kernel(const CcvAttn p) {
     static_assert(NQB == 1 || NQB == 2, "one or two 32-query blocks per wave");
+    static_assert(!(MASKED && NQB == 1), "the masked tiled form stays at 64 queries per wave: its 32-query instance gave wrong results for partially "
+                                         "masked second key blocks of a tile (round 4, not understood) and is not built");
     constexpr int QW = 128 * NQB;        // queries per workgroup
     static_assert(!(MASKED && TWO), "the two-context form has no mask path");
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * 2 * KT * 128];  // [stage][K|V][64 rows][128 B]
@@ -1633,10 +1635,11 @@ extern "C" int64_t ccv_attn_split_ws_bytes(const CcvAttn* pp) {
 }
 
 // CCV_ATTN2_Q32: bit mask of the tiled-attention forms that run with 32 queries per wave (attn2_kernel<.., .., 1>: four workgroups per CU)
-// instead of 64: 1 = two-context cross attention, 2 = unmasked single context, 4 = masked tiled (A/B aid; default below)
+// instead of 64: 1 = two-context cross attention, 2 = unmasked single context (the masked tiled form has no such instance).  Default 3:
+// +1.0 % frames/s one clip at a time, within the noise with two in flight (profiles/r04_ab_switches.txt); CCV_ATTN2_Q32=0 is the A/B arm.
 static int attn2_q32(const CcvAttn& p) {
-    static const int v = [] { const char* e = getenv("CCV_ATTN2_Q32"); return e ? atoi(e) & 7 : 0; }();
-    return p.variant == 7 ? 7 : v;      // variant 7: as 0, every tiled form with 32 queries per wave (tests)
+    static const int v = [] { const char* e = getenv("CCV_ATTN2_Q32"); return e ? atoi(e) & 3 : 3; }();
+    return p.variant == 7 ? 3 : (p.variant == 8 ? 0 : v);      // variants 7 / 8: as 0 with 32 / 64 queries per wave whatever the default (tests)
 }
 
 static bool two_ctx_on() {   // CCV_ATTN_TWO=0: two-context calls on the first-generation kernel (A/B aid)
@@ -1652,7 +1655,7 @@ static CcvAttn fold_shared_kv(const CcvAttn& in) {
     static const bool on = [] { const char* e = getenv("CCV_ATTN_FOLD"); return !(e && e[0] == '0'); }();
     CcvAttn p = in;
     const bool shared = p.k_bsi == 0 && p.v_bsi == 0 && (!p.k2 || (p.k2_bsi == 0 && p.v2_bsi == 0));
-    if (on && shared && p.inner > 1 && p.B % p.inner == 0 && !p.mask_bits && !p.kreg && p.perm_w == 0 && (p.variant == 0 || p.variant == 7) &&
+    if (on && shared && p.inner > 1 && p.B % p.inner == 0 && !p.mask_bits && !p.kreg && p.perm_w == 0 && (p.variant == 0 || p.variant >= 7) &&
         p.q_bsi == (int64_t)p.Lq * p.q_ls && p.o_bsi == (int64_t)p.Lq * p.o_ls && (long)p.inner * p.Lq < (1l << 30) && p.Lq > 16) {
         p.Lq *= p.inner;
         p.B /= p.inner;
@@ -1677,7 +1680,7 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
     CCV_REQUIRE(!p.mask_bits || p.mask_nb > 0, CCV_EINVAL, "ccv_attn_fwd: mask_nb must be positive");
     CCV_REQUIRE(!p.tile_flags || p.flags_ktiles * KT >= p.Lk, CCV_EINVAL, "ccv_attn_fwd: flags_ktiles too small");
     CCV_REQUIRE(!(p.variant >= 3 && p.variant <= 6) || (p.wave_bits && !p.k2), CCV_EINVAL, "ccv_attn_fwd: variants 3-6 need wave_bits and a single context");
-    CCV_REQUIRE(p.variant >= 0 && p.variant <= 7, CCV_EINVAL, "ccv_attn_fwd: unknown variant %d", p.variant);
+    CCV_REQUIRE(p.variant >= 0 && p.variant <= 8, CCV_EINVAL, "ccv_attn_fwd: unknown variant %d", p.variant);
     CCV_REQUIRE(!p.wave_bits || (p.mask_bits && (long)p.wave_words * 32 * 32 >= p.Lk), CCV_EINVAL,
                 "ccv_attn_fwd: wave_bits needs mask_bits and wave_words covering Lk");
     CCV_REQUIRE(!p.kreg || p.vreg, CCV_EINVAL, "ccv_attn_fwd: kreg without vreg");
@@ -1770,13 +1773,12 @@ extern "C" int ccv_attn_fwd(const CcvAttn* pp, void* stream) {
             hipLaunchKernelGGL(attn_sparse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
         }
         else if (p.mask_bits) {
-            if (attn2_q32(p) & 4) hipLaunchKernelGGL((attn2_kernel<true, false, 1>), grid2h, dim3(256), 0, st, p);
-            else                 hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
+            hipLaunchKernelGGL(attn2_kernel<true>, grid2, dim3(256), 0, st, p);
         } else {
             if (attn2_q32(p) & 2) hipLaunchKernelGGL((attn2_kernel<false, false, 1>), grid2h, dim3(256), 0, st, p);
             else                 hipLaunchKernelGGL(attn2_kernel<false>, grid2, dim3(256), 0, st, p);
         }
-    } else if ((p.variant == 0 || p.variant == 7) && p.k2 && !p.mask_bits && p.perm_w == 0 && two_ctx_on()) {   // two contexts (text + gated image tokens)
+    } else if ((p.variant == 0 || p.variant >= 7) && p.k2 && !p.mask_bits && p.perm_w == 0 && two_ctx_on()) {   // two contexts (text + gated image tokens)
         const long nwg2 = (long)((p.Lq + 255) / 256) * p.H * p.B;
         CCV_REQUIRE(nwg2 < (1l << 31), CCV_ESHAPE, "ccv_attn_fwd: grid too large");
         if (attn2_q32(p) & 1) {

@@ -228,7 +228,8 @@ typedef struct CcvAttn {
                             64-query groups upwards and the tiled masked kernel below that);
                          4 / 5: as 3, the workgroup-shared sparse kernel with 8 / 4 waves (256 / 128 queries) per workgroup;
                          6: as 3, the per-wave sparse kernel (every wave streams its own K / V blocks);
-                         7: as 0, the tiled kernels with 32 queries per wave (four workgroups per CU) whatever the library's default is */
+                         7 / 8: as 0, the unmasked tiled kernels with 32 / 64 queries per wave (four / two workgroups per CU) whatever the
+                            library's default is (bit-identical results; tests) */
     uint32_t* queue_counters; /* NULL or 8 uint32 that the caller ZEROED on `stream` before the call: the work-queue counters of
                               * the persistent sparse kernel (wave_bits path).  With caller-owned counters the call keeps no
                               * state in the library, so launches may overlap freely on different streams (two clips in

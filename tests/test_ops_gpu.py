@@ -408,29 +408,24 @@ def test_attention_dual_context_shapes(ops, Lq, Lk2, per_frame):
         ki = ki.repeat_interleave(frames, 0)
     ref = ref_attn(qf, kt[:, :, 0], kt[:, :, 1]) + gate * ref_attn(qf, ki[:, :, 0], ki[:, :, 1])
     assert_close(out.reshape(B, Lq, H, 64), ref, 1.5e-2, f"dual context Lq={Lq} Lk2={Lk2} per_frame={per_frame}")
-    # 32 queries per wave (attn2_kernel<.., .., 1>, variant 7): the same arithmetic per query -> bit for bit
-    out32 = ops.attention(q, kv_t, kv_t[:, C:], B=B, inner=frames, H=H, Lq=Lq, Lk=77,
-                          q_str=(frames * Lq * C, Lq * C, C), k_str=(77 * 2 * C, 0, 2 * C), v_str=(77 * 2 * C, 0, 2 * C),
-                          k2=kv_i, v2=kv_i[:, C:], k2_str=st_i, v2_str=st_i, Lk2=Lk2, gate2=gate, variant=7)
-    assert torch.equal(out, out32)
+    # 32 queries per wave (attn2_kernel<.., .., 1>, variant 7) and 64 (variant 8): the same arithmetic per query -> bit for bit
+    o78 = [ops.attention(q, kv_t, kv_t[:, C:], B=B, inner=frames, H=H, Lq=Lq, Lk=77,
+                         q_str=(frames * Lq * C, Lq * C, C), k_str=(77 * 2 * C, 0, 2 * C), v_str=(77 * 2 * C, 0, 2 * C),
+                         k2=kv_i, v2=kv_i[:, C:], k2_str=st_i, v2_str=st_i, Lk2=Lk2, gate2=gate, variant=vv) for vv in (7, 8)]
+    assert torch.equal(o78[0], o78[1]) and torch.equal(out, o78[0])
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk", [(3, 5, 1024, 1024), (2, 2, 200, 77), (1, 3, 130, 333)])
 def test_attention_32_queries_per_wave_equals_64(ops, B, H, Lq, Lk):
-    """attn2_kernel<.., .., 1> (round 4: 32 queries per wave, four workgroups per CU) against the 64-query form: unmasked, and masked
-    with tile flags and register tokens (the tiled masked kernel), ragged lengths -- bit-identical."""
+    """attn2_kernel<.., .., 1> (round 4: 32 queries per wave, four workgroups per CU; variant 7) against the 64-query form (variant 8),
+    unmasked, ragged lengths: bit-identical, and both within the usual distance of torch fp32.  (The masked tiled kernel has no 32-query
+    instance.)"""
     q, k, v = rnd(B, Lq, H, 64, seed=220), rnd(B, Lk, H, 64, seed=221), rnd(B, Lk, H, 64, seed=222)
     C = H * 64
     kw = dict(B=B, inner=1, H=H, Lq=Lq, Lk=Lk, q_str=(Lq * C, 0, C), k_str=(Lk * C, 0, C), v_str=(Lk * C, 0, C))
-    assert torch.equal(ops.attention(q, k, v, variant=0, **kw), ops.attention(q, k, v, variant=7, **kw))
-    if Lq == Lk:
-        g = torch.Generator().manual_seed(223)
-        mask = (torch.rand(1, Lq, Lk, generator=g) < 0.1)
-        mask[:, :200, 300:600] = False
-        mp = ops.pack_mask(mask.to(dev()))
-        reg = rnd(4, C, seed=224)
-        kwm = dict(kw, mask_bits=mp[0], tile_flags=mp[1], mask_nb=1, kreg=reg, vreg=reg)
-        assert torch.equal(ops.attention(q, k, v, variant=0, **kwm), ops.attention(q, k, v, variant=7, **kwm))
+    a7, a8 = ops.attention(q, k, v, variant=7, **kw), ops.attention(q, k, v, variant=8, **kw)
+    assert torch.equal(a7, a8)
+    assert_close(a7.reshape(B, Lq, H, 64), ref_attn(q.float(), k.float(), v.float()), 1.5e-2, f"32 queries per wave {B},{H},{Lq},{Lk}")
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
