@@ -608,7 +608,9 @@ def main(argv=None, hooks=None):
     else:
         device, sync = hooks["device"], hooks.get("sync", lambda: None)
     dist = None
-    if world > 1:
+    # CCV_BENCH_RCCL_1RANK=1 (launched by torch.distributed.run with one rank): the N-rank code path -- RCCL communicator on the rank's
+    # device, identity check, barriers, per-rank times, the final all_gather_into_tensor -- on a one-GPU box
+    if world > 1 or (on_gpu and "WORLD_SIZE" in os.environ and os.environ.get("CCV_BENCH_RCCL_1RANK") == "1"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
