@@ -249,6 +249,248 @@ float run_piped(float* out, int iters) {
     return ms;
 }
 
+// Two 32-query blocks A and B per wave, half a step apart: while the softmax of one block issues its vector instructions, the other block's eight
+// independent MFMAs (PV of its previous step, QK of its next) go into the gaps.  The softmax is written in two parts so that the rare rescale
+// branch does not separate the MFMAs from the exponentials they are interleaved with.
+__device__ __forceinline__ void sm_head(const f32x16& sa, float sl2, float& m_r, float& l_r, f32x16 (&oa)[2], float& m_use) {
+    float tmax = NEG_INF;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sa[i]), sa[i + 1]);
+    const uint32_t tb = __float_as_uint(tmax);
+    const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(sw[0]), "v"(sw[1]));
+    tmax *= sl2;
+    const float m_new = fmaxf(m_r, tmax);
+    m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    if (!__all(m_new == m_r)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
+        l_r *= alpha;
+        oa[0] = oa[0] * alpha;
+        oa[1] = oa[1] * alpha;
+        m_r = m_new;
+    }
+}
+__device__ __forceinline__ void sm_tail(const f32x16& sa, float sl2, float m_use, float& l_r, bf16x8 (&pfo)[2]) {
+    const f32x2 scale2 = {sl2, sl2}, negm2 = {-m_use, -m_use};
+    f32x2 psum2 = {0.f, 0.f};
+    float pv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const f32x2 s2 = {sa[i], sa[i + 1]};
+        const f32x2 x = __builtin_elementwise_fma(s2, scale2, negm2);
+        const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        pv[i] = e[0];
+        pv[i + 1] = e[1];
+        psum2 = psum2 + e;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+        pfo[s2] = ccv_opnd8(pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3], pv[8 * s2 + 4], pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]);
+    l_r += psum2[0] + psum2[1];
+}
+
+template <int OCC, int SCHED>
+__global__ __launch_bounds__(256, OCC) void twoblock_kernel(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 kf[4], qa[4], qb[4], vf[2][2];
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 8; ++j) {
+            kf[s][j] = (ccv_opnd_t)(seed * (float)((lane + s + j) & 7) * 0.01f);
+            qa[s][j] = (ccv_opnd_t)(seed * (float)((lane * 3 + s + j) & 7) * 0.01f);
+            qb[s][j] = (ccv_opnd_t)(seed * (float)((lane * 5 + s + j) & 7) * 0.01f);
+        }
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int j = 0; j < 8; ++j) vf[a][b][j] = (ccv_opnd_t)(seed * (float)((lane + a + 2 * b + j) & 3) * 0.1f);
+    f32x16 oA[2], oB[2], sA, sB;
+    for (int i = 0; i < 16; ++i) {
+        oA[0][i] = oA[1][i] = oB[0][i] = oB[1][i] = 0.f;
+        sA[i] = seed * (float)i;
+        sB[i] = seed * (float)(15 - i);
+    }
+    float mA = NEG_INF, lA = 0.f, mB = NEG_INF, lB = 0.f;
+    bf16x8 pA[2], pB[2];
+    for (int j = 0; j < 8; ++j) pA[0][j] = pA[1][j] = pB[0][j] = pB[1][j] = (ccv_opnd_t)0.5f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        float mu;
+        // phase X: softmax of A's scores; MFMAs: PV of B (previous step), QK of B (this step)
+        sm_head(sA, 0.18f, mA, lA, oA, mu);
+        {
+            f32x16 t = ccv_mfma_32x32x16(kf[0], qb[0], zero);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) oB[d] = ccv_mfma_32x32x16(vf[d][s2], pB[s2], oB[d]);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) t = ccv_mfma_32x32x16(kf[s], qb[s], t);
+            sm_tail(sA, 0.18f, mu, lA, pA);
+            sB = t;
+            if (SCHED) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, SCHED, 0);
+                }
+            }
+        }
+        // phase Y: softmax of B's scores; MFMAs: PV of A (this step), QK of A (next step)
+        sm_head(sB, 0.18f, mB, lB, oB, mu);
+        {
+            f32x16 t = ccv_mfma_32x32x16(kf[0], qa[0], zero);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) oA[d] = ccv_mfma_32x32x16(vf[d][s2], pA[s2], oA[d]);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) t = ccv_mfma_32x32x16(kf[s], qa[s], t);
+            sm_tail(sB, 0.18f, mu, lB, pB);
+            sA = t;
+            if (SCHED) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, SCHED, 0);
+                }
+            }
+        }
+    }
+    float acc = lA + mA + lB + mB;
+    for (int i = 0; i < 16; ++i) acc += oA[0][i] + oA[1][i] + oB[0][i] + oB[1][i] + sA[i] + sB[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+// The same two-block schedule with the order pinned in the source: one MFMA, then a slice of the other block's softmax, sched_barrier(0) between
+// the slices (nothing moves across).  o = the softmax block's accumulators (rescale), po / pi = its P fragments out, the other block's in.
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void pinned_phase(f32x16& s_sm, float& m_r, float& l_r, f32x16 (&o_sm)[2], bf16x8 (&p_out)[2],
+                                             f32x16 (&o_mm)[2], const bf16x8 (&p_in)[2], f32x16& s_out, const bf16x8 (&kf)[4], const bf16x8 (&qf)[4],
+                                             const bf16x8 (&vf)[2][2], float sl2) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // slices 0, 1: PV MFMAs of the other block; row maximum of this one
+    o_mm[0] = ccv_mfma_32x32x16(vf[0][0], p_in[0], o_mm[0]);
+    float t0 = fmaxf(fmaxf(s_sm[0], s_sm[1]), s_sm[2]), t1 = fmaxf(fmaxf(s_sm[3], s_sm[4]), s_sm[5]);
+    t0 = fmaxf(fmaxf(t0, s_sm[6]), s_sm[7]);
+    t1 = fmaxf(fmaxf(t1, s_sm[8]), s_sm[9]);
+    PIN();
+    o_mm[0] = ccv_mfma_32x32x16(vf[0][1], p_in[1], o_mm[0]);
+    t0 = fmaxf(fmaxf(t0, s_sm[10]), s_sm[11]);
+    t1 = fmaxf(fmaxf(t1, s_sm[12]), s_sm[13]);
+    float tmax = fmaxf(fmaxf(fmaxf(t0, t1), s_sm[14]), s_sm[15]);
+    const uint32_t tb = __float_as_uint(tmax);
+    const auto sw = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(sw[0]), "v"(sw[1]));
+    tmax *= sl2;
+    const float m_new = fmaxf(m_r, tmax);
+    const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+    PIN();
+    if (!__all(m_new == m_r)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_r - m_use);
+        l_r *= alpha;
+        o_sm[0] = o_sm[0] * alpha;
+        o_sm[1] = o_sm[1] * alpha;
+        m_r = m_new;
+    }
+    PIN();
+    const f32x2 scale2 = {sl2, sl2}, negm2 = {-m_use, -m_use};
+    f32x2 psum2 = {0.f, 0.f};
+    float pv[16];
+    f32x16 t;
+#define EXP4(i0)                                                                                             \
+    _Pragma("unroll") for (int i = i0; i < i0 + 4; i += 2) {                                                 \
+        const f32x2 s2 = {s_sm[i], s_sm[i + 1]};                                                             \
+        const f32x2 x = __builtin_elementwise_fma(s2, scale2, negm2);                                        \
+        const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};                        \
+        pv[i] = e[0];                                                                                        \
+        pv[i + 1] = e[1];                                                                                    \
+        psum2 = psum2 + e;                                                                                   \
+    }
+    o_mm[1] = ccv_mfma_32x32x16(vf[1][0], p_in[0], o_mm[1]);
+    EXP4(0)
+    PIN();
+    o_mm[1] = ccv_mfma_32x32x16(vf[1][1], p_in[1], o_mm[1]);
+    EXP4(4)
+    PIN();
+    t = ccv_mfma_32x32x16(kf[0], qf[0], zero);
+    EXP4(8)
+    PIN();
+    t = ccv_mfma_32x32x16(kf[1], qf[1], t);
+    EXP4(12)
+    PIN();
+    t = ccv_mfma_32x32x16(kf[2], qf[2], t);
+    p_out[0] = ccv_opnd8(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7]);
+    PIN();
+    t = ccv_mfma_32x32x16(kf[3], qf[3], t);
+    p_out[1] = ccv_opnd8(pv[8], pv[9], pv[10], pv[11], pv[12], pv[13], pv[14], pv[15]);
+    l_r += psum2[0] + psum2[1];
+    PIN();
+    s_out = t;
+#undef EXP4
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void pinned_kernel(float* out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 kf[4], qa[4], qb[4], vf[2][2];
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 8; ++j) {
+            kf[s][j] = (ccv_opnd_t)(seed * (float)((lane + s + j) & 7) * 0.01f);
+            qa[s][j] = (ccv_opnd_t)(seed * (float)((lane * 3 + s + j) & 7) * 0.01f);
+            qb[s][j] = (ccv_opnd_t)(seed * (float)((lane * 5 + s + j) & 7) * 0.01f);
+        }
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+            for (int j = 0; j < 8; ++j) vf[a][b][j] = (ccv_opnd_t)(seed * (float)((lane + a + 2 * b + j) & 3) * 0.1f);
+    f32x16 oA[2], oB[2], sA, sB;
+    for (int i = 0; i < 16; ++i) {
+        oA[0][i] = oA[1][i] = oB[0][i] = oB[1][i] = 0.f;
+        sA[i] = seed * (float)i;
+        sB[i] = seed * (float)(15 - i);
+    }
+    float mA = NEG_INF, lA = 0.f, mB = NEG_INF, lB = 0.f;
+    bf16x8 pA[2], pB[2];
+    for (int j = 0; j < 8; ++j) pA[0][j] = pA[1][j] = pB[0][j] = pB[1][j] = (ccv_opnd_t)0.5f;
+    for (int it = 0; it < iters; ++it) {
+        pinned_phase(sA, mA, lA, oA, pA, oB, pB, sB, kf, qb, vf, 0.18f);     // softmax A | PV B (previous step), QK B
+        pinned_phase(sB, mB, lB, oB, pB, oA, pA, sA, kf, qa, vf, 0.18f);     // softmax B | PV A, QK A (next step)
+    }
+    float acc = lA + mA + lB + mB;
+    for (int i = 0; i < 16; ++i) acc += oA[0][i] + oA[1][i] + oB[0][i] + oB[1][i] + sA[i] + sB[i];
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int OCC>
+float run_pinned(float* out, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    pinned_kernel<OCC><<<256 * OCC, 256>>>(out, 16, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    pinned_kernel<OCC><<<256 * OCC, 256>>>(out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+template <int OCC, int SCHED>
+float run_twoblock(float* out, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    twoblock_kernel<OCC, SCHED><<<256 * OCC, 256>>>(out, 16, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    twoblock_kernel<OCC, SCHED><<<256 * OCC, 256>>>(out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
 template <int MODE, int OCC>
 float run(float* out, int blocks, int iters) {
     hipEvent_t e0, e1;
@@ -312,6 +554,15 @@ int main(int argc, char** argv) {
         printf("  source order only:              %6.0f %6.0f %6.0f\n", run_piped<1, 0, 0>(out, iters) * k, run_piped<2, 0, 0>(out, iters) * k / 2, run_piped<4, 0, 0>(out, iters) * k / 4);
         printf("  1 MFMA : 8 vector instructions: %6.0f %6.0f %6.0f\n", run_piped<1, 1, 8>(out, iters) * k, run_piped<2, 1, 8>(out, iters) * k / 2, run_piped<4, 1, 8>(out, iters) * k / 4);
         printf("  1 MFMA : 14 vector instructions:%6.0f %6.0f %6.0f\n", run_piped<1, 1, 14>(out, iters) * k, run_piped<2, 1, 14>(out, iters) * k / 2, run_piped<4, 1, 14>(out, iters) * k / 4);
+    }
+    printf("# two query blocks per wave half a step apart (softmax of one among the other's 8 MFMAs); cycles per 32-query wave-step at 2.4 GHz, 1 / 2 waves per SIMD\n");
+    {
+        const double k = 1e6 / iters * 2.4 / 2;      // an iteration = two wave-steps
+        printf("  source order:                    %6.0f %6.0f\n", run_twoblock<1, 0>(out, iters) * k, run_twoblock<2, 0>(out, iters) * k / 2);
+        printf("  1 MFMA : 5 vector instructions:  %6.0f %6.0f\n", run_twoblock<1, 5>(out, iters) * k, run_twoblock<2, 5>(out, iters) * k / 2);
+        printf("  1 MFMA : 6 vector instructions:  %6.0f %6.0f\n", run_twoblock<1, 6>(out, iters) * k, run_twoblock<2, 6>(out, iters) * k / 2);
+        printf("  1 MFMA : 7 vector instructions:  %6.0f %6.0f\n", run_twoblock<1, 7>(out, iters) * k, run_twoblock<2, 7>(out, iters) * k / 2);
+        printf("  order pinned in the source:      %6.0f %6.0f\n", run_pinned<1>(out, iters) * k, run_pinned<2>(out, iters) * k / 2);
     }
     hipFree(out);
     return 0;
