@@ -27,6 +27,54 @@ constexpr int V_ROW = 192;      // bytes per V row in LDS (128 + 64 pad: tr read
 constexpr int VT_ROW = 144;     // bytes per V^T row in LDS (variant 1)
 constexpr float NEG_INF = -__builtin_inff();
 
+// First stored row of the 32-token patch that starts at permuted index k0 (csrc/ccv_common.h: ccv_patch_row with within = 0), in wave-uniform
+// scalar arithmetic: shifts for the shipped power-of-two latent sizes instead of ~22-instruction scalar divisions per block.
+struct PatchGeom {
+    int hw, w, ppr, quads, pow2, sh_hw, sh_ppr;
+};
+__device__ __forceinline__ PatchGeom patch_geom(int perm_hw, int perm_w) {
+    PatchGeom g;
+    g.hw = perm_hw;
+    g.w = perm_w;
+    g.ppr = perm_w >> 3;
+    g.pow2 = perm_w && (perm_hw & (perm_hw - 1)) == 0 && (g.ppr & (g.ppr - 1)) == 0;
+    g.quads = perm_w && g.ppr > 2 && !(g.ppr & 1) && !((perm_hw / perm_w) & 7);      // 2x2 quads of patches (ccv_patch_row; two patches per row: the same order)
+    g.sh_hw = g.pow2 ? __builtin_ctz(perm_hw) : 0;
+    g.sh_ppr = g.pow2 ? __builtin_ctz(g.ppr) : 0;
+    return g;
+}
+__device__ __forceinline__ int patch_first_row(int k0, const PatchGeom& g) {
+    int f, patch, py, px;
+    if (g.pow2) {
+        f = k0 >> g.sh_hw;
+        patch = (k0 & (g.hw - 1)) >> 5;
+    } else {
+        f = k0 / g.hw;
+        patch = (k0 - f * g.hw) >> 5;
+    }
+    if (g.quads) {
+        const int quad = patch >> 2, sub = patch & 3;
+        int qy, qx;
+        if (g.pow2) {
+            qy = quad >> (g.sh_ppr - 1);
+            qx = quad & ((g.ppr >> 1) - 1);
+        } else {
+            const int qpr = g.ppr >> 1;
+            qy = quad / qpr;
+            qx = quad - qy * qpr;
+        }
+        py = 2 * qy + (sub >> 1);
+        px = 2 * qx + (sub & 1);
+    } else if (g.pow2) {
+        py = patch >> g.sh_ppr;
+        px = patch & (g.ppr - 1);
+    } else {
+        py = patch / g.ppr;
+        px = patch - py * g.ppr;
+    }
+    return f * g.hw + py * 4 * g.w + px * 8;
+}
+
 struct Seg {            // one key/value segment of a softmax pass
     const uint16_t* k;
     const uint16_t* v;
@@ -731,9 +779,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
     const int ngroups = (p.Lq + 63) >> 6;
     const int nbh = p.B * p.H;
     const int k_ls32 = (int)p.k_ls, v_ls32 = (int)p.v_ls;
-    const int ppr_ = p.perm_w >> 3;
-    const bool perm_pow2 = p.perm_w && (p.perm_hw & (p.perm_hw - 1)) == 0 && (ppr_ & (ppr_ - 1)) == 0;
-    const int sh_hw = perm_pow2 ? __builtin_ctz(p.perm_hw) : 0, sh_ppr = perm_pow2 ? __builtin_ctz(ppr_) : 0;
+    const PatchGeom pgeom = patch_geom(p.perm_hw, p.perm_w);
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     xcc = (use_xcd_queues == 2) ? (int)(blockIdx.x & 7) : (xcc & 7);   // 2 (A/B aid): the round-robin dispatch label instead
@@ -826,22 +872,7 @@ __global__ __launch_bounds__(256, 2) void attn_sparse_kernel(const SparseArgs p)
         } else {
             const int k0 = 32 * blk;
             int base = k0;
-            if (p.perm_w) {   // first stored row of the patch (wave-uniform scalar arithmetic)
-                int f, patch, py, px;
-                if (perm_pow2) {   // every shipped latent size: two shifts instead of two ~22-instruction scalar divisions per block
-                    f = k0 >> sh_hw;
-                    patch = (k0 & (p.perm_hw - 1)) >> 5;
-                    py = patch >> sh_ppr;
-                    px = patch & ((p.perm_w >> 3) - 1);
-                } else {
-                    f = k0 / p.perm_hw;
-                    patch = (k0 - f * p.perm_hw) >> 5;
-                    const int ppr = p.perm_w >> 3;
-                    py = patch / ppr;
-                    px = patch - py * ppr;
-                }
-                base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
-            }
+            if (p.perm_w) base = patch_first_row(k0, pgeom);   // first stored row of the patch (wave-uniform scalar arithmetic)
             // through the slice's buffer descriptors: the lane's 32-bit offsets are fixed for the item, the block's first stored row rides
             // in the scalar offset (no vector address arithmetic per block); rows past the last key of a ragged last block (raster order
             // only: a patch-ordered sequence is a whole number of 32-key patches, checked on the host) fall outside the descriptor's
@@ -1070,9 +1101,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
     const int ngroups = (p.Lq + GQ - 1) / GQ;
     const int ngroups64 = (p.Lq + 63) >> 6;
     const int nbh = p.B * p.H;
-    const int ppr_ = p.perm_w >> 3;
-    const bool perm_pow2 = p.perm_w && (p.perm_hw & (p.perm_hw - 1)) == 0 && (ppr_ & (ppr_ - 1)) == 0;
-    const int sh_hw = perm_pow2 ? __builtin_ctz(p.perm_hw) : 0, sh_ppr = perm_pow2 ? __builtin_ctz(ppr_) : 0;
+    const PatchGeom pgeom = patch_geom(p.perm_hw, p.perm_w);
     const int parts = max(p.split_parts, 1);
     const int rank0 = parts > 1 ? min(p.split_rank0, ngroups) : ngroups;        // ranks >= rank0 come in `parts` parts
     const long q_whole = (long)nbh * rank0;
@@ -1192,21 +1221,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_shared_kernel(const SparseArg
         } else {
             const int k0 = 32 * blk;
             int base = k0;
-            if (p.perm_w) {   // first stored row of the 4x8-pixel patch (wave-uniform scalar arithmetic)
-                int f, patch, py, px;
-                if (perm_pow2) {
-                    f = k0 >> sh_hw;
-                    patch = (k0 & (p.perm_hw - 1)) >> 5;
-                    py = patch >> sh_ppr;
-                    px = patch & (ppr_ - 1);
-                } else {
-                    f = k0 / p.perm_hw;
-                    patch = (k0 - f * p.perm_hw) >> 5;
-                    py = patch / ppr_;
-                    px = patch - py * ppr_;
-                }
-                base = f * p.perm_hw + py * 4 * p.perm_w + px * 8;
-            }
+            if (p.perm_w) base = patch_first_row(k0, pgeom);   // first stored row of the 4x8-pixel patch (wave-uniform scalar arithmetic)
             const int so = base * ls32 * 2;
 #pragma unroll
             for (int t = 0; t < PP; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_o, (lptr_t*)(dst + t * 1024), 16, poff32[t], so, 0, 0);

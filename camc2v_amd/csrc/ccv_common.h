@@ -161,13 +161,27 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
-// permuted token index -> stored row: frames of `hw` tokens, `w` wide, walked in 4x8-pixel patches (w == 0: identity)
+// permuted token index -> stored row: frames of `hw` tokens, `w` wide, walked in 4x8-pixel patches (w == 0: identity).  Patches are
+// numbered in 2x2 QUADS (8x16 pixels, quads row-major, patches row-major inside a quad) when the frame has an even number of patch rows and
+// columns, else row-major: 128 consecutive tokens -- the queries of one workgroup of the shared-K/V attention kernel -- are then a compact
+// 8x16-pixel block whatever the camera does.  (Round 4; before: four patches in a row, a 4x32 strip, whose queries see nearly the same key
+// blocks only when the epipolar lines run along the strip: key blocks needed per 128 queries at 32x32 latents, of 512: benchmark camera
+// 225 -> 211, vertical translation 506 -> 260, forward motion 476 -> 297.)  16x16 latents: the same order either way.
 __host__ __device__ __forceinline__ int ccv_patch_row(int idx, int hw, int w) {
     if (w == 0) return idx;
     const int f = idx / hw, rem = idx - f * hw;
     const int patch = rem >> 5, within = rem & 31;
     const int ppr = w >> 3;                       // patches per patch-row
-    const int py = patch / ppr, px = patch - py * ppr;
+    int py, px;
+    if (ppr > 2 && !(ppr & 1) && !((hw / w) & 7)) {      // (two patches per row: quad order = row-major order)
+        const int quad = patch >> 2, sub = patch & 3, qpr = ppr >> 1;
+        const int qy = quad / qpr, qx = quad - qy * qpr;
+        py = 2 * qy + (sub >> 1);
+        px = 2 * qx + (sub & 1);
+    } else {
+        py = patch / ppr;
+        px = patch - py * ppr;
+    }
     return f * hw + (py * 4 + (within >> 3)) * w + px * 8 + (within & 7);
 }
 

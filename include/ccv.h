@@ -220,7 +220,8 @@ typedef struct CcvAttn {
                               * out in this order (longest first) so that the last waves to finish hold the cheapest groups */
     const uint16_t* kreg; const uint16_t* vreg; int32_t nreg;
     int32_t perm_hw, perm_w; /* token order of q/k/v/o rows and of the mask: 0 = as stored; otherwise the kernel walks each
-                              * frame (perm_hw tokens, perm_w wide) in 4x8-pixel patches (index -> row map in ccv_patch_row);
+                              * frame (perm_hw tokens, perm_w wide) in 4x8-pixel patches, the patches in 2x2 quads when the frame
+                              * has even numbers of patch rows and columns, else row-major (index -> row map: ccv_patch_row);
                               * the mask must have been built with the same values */
     int32_t variant;  /* 0: default (LDS-DMA kernel, 64 queries per wave; unmasked two-context calls run both softmaxes in it);
                          1: first-generation kernel, V^T via ds_read_b64_tr_b16; 2: same, V transposed while staging;

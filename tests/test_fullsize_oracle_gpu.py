@@ -166,10 +166,16 @@ def test_hip_mask_bits_equal_the_reference_masks_full_size(golden_dir):
             assert np.array_equal(raw, fb[f"mask256_d{d}_bits"][0]), f"d={d}: positions"
         if ops.patch_order_ok(H, H):
             # patch order permutes rows (and bit columns) within each frame: frame f, pixel (r, c) sits at
-            # f*HW + patch*32 + (r%4)*8 + c%8 with patch = (r//4)*(W//8) + c//8
+            # f*HW + patch*32 + (r%4)*8 + c%8; patch = (r//4)*(W//8) + c//8, or -- even numbers of patch rows and columns --
+            # 4 * quad + 2 * (patch row % 2) + patch column % 2 with the 2x2 quads of patches row-major (csrc/ccv_common.h: ccv_patch_row)
             pbits = ops.epipolar_mask_bits(F, 16, H, H, d, patch_order=True)[0]
             gp = _row_popcounts(pbits[0])
             r, c = np.meshgrid(np.arange(H), np.arange(H), indexing="ij")
-            pos = ((r // 4) * (H // 8) + c // 8) * 32 + (r % 4) * 8 + c % 8
+            pr, pc = r // 4, c // 8
+            if (H // 8) % 2 == 0 and (H // 4) % 2 == 0:
+                patch = ((pr // 2) * (H // 16) + pc // 2) * 4 + (pr % 2) * 2 + pc % 2
+            else:
+                patch = pr * (H // 8) + pc
+            pos = patch * 32 + (r % 4) * 8 + c % 8
             perm = (np.arange(16)[:, None] * H * H + pos.reshape(-1)[None]).reshape(-1)
             assert np.array_equal(gp[perm], got), f"d={d}: patch-order rows hold different bits than raster-order rows"

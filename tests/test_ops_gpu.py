@@ -39,7 +39,12 @@ def ccv_patch_row_py(idx, hw, w):
     f, rem = divmod(idx, hw)
     patch, within = rem >> 5, rem & 31
     ppr = w >> 3
-    py, px = divmod(patch, ppr)
+    if ppr % 2 == 0 and (hw // w) % 8 == 0:      # 2x2 quads of patches, quads row-major
+        quad, sub = patch >> 2, patch & 3
+        qy, qx = divmod(quad, ppr >> 1)
+        py, px = 2 * qy + (sub >> 1), 2 * qx + (sub & 1)
+    else:
+        py, px = divmod(patch, ppr)
     return f * hw + (py * 4 + (within >> 3)) * w + px * 8 + (within & 7)
 
 

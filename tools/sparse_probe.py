@@ -16,7 +16,28 @@ torch.set_grad_enabled(False)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 T, px = 16, 256
 K = torch.tensor([[px / 2, 0, px / 2], [0, px / 2, px / 2], [0, 0, 1.0]], device=dev).repeat(1, T, 1, 1)
-w2c = camera.synthetic_trajectory(1, T, dev)
+motion = os.environ.get("SPARSE_PROBE_CAMERA", "benchmark")     # benchmark (yaw + x / z translation) | vertical | forward | orbit
+if motion == "benchmark":
+    w2c = camera.synthetic_trajectory(1, T, dev)
+else:
+    fr = torch.arange(T, dtype=torch.float32)
+    c2w = torch.eye(4).repeat(T, 1, 1)
+    if motion == "vertical":
+        c2w[:, 1, 3] = 0.05 * fr
+    elif motion == "forward":
+        c2w[:, 2, 3] = 0.08 * fr
+    elif motion == "orbit":      # yaw + pitch + translation along all three axes
+        import math
+        for i in range(T):
+            a, b = 0.03 * i, 0.02 * i
+            ry = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+            rx = torch.tensor([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+            c2w[i, :3, :3] = ry @ rx
+        c2w[:, 0, 3], c2w[:, 1, 3], c2w[:, 2, 3] = 0.04 * fr, 0.03 * fr, 0.03 * fr
+    else:
+        raise SystemExit(f"SPARSE_PROBE_CAMERA={motion!r}")
+    w2c = torch.linalg.inv(c2w).unsqueeze(0).to(dev)
+print(f"# camera: {motion}", flush=True)
 rel = camera.relative_c2w(w2c, torch.zeros(1, dtype=torch.long, device=dev))
 F = camera.pairwise_fundamental(K, rel, generator=torch.Generator(device=dev).manual_seed(3))
 packed = camera.epipolar_masks_packed(F, T, px, px)
