@@ -153,16 +153,19 @@ __device__ __forceinline__ float4 ccv_load4(const void* x, long idx4) {
 // a third of gn_apply's instructions, and vector instructions of a streaming kernel are not free beside another clip's MFMAs on the same SIMD);
 // the results are rounded to bf16 by every caller.  Same limits: x -> -inf gives -0, x -> +inf gives x.
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below fp32 rounding of the GELU product
-// and far below the bf16 rounding of the stored result); ~12 VALU + 1 v_exp + 1 v_rcp instead of libm erff.
-__device__ __forceinline__ float erf_fast(float x) {
+// erf-GELU x Phi(x) from Abramowitz-Stegun 7.1.26 (erf(z) = 1 - P(t) exp(-z^2), t = 1 / (1 + p z), |abs err| <= 1.5e-7: below the fp32 rounding of
+// the product and far below the bf16 rounding of the stored result), written on the tail q = Phi(-|x|) = 0.5 P(t) exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2):
+// Phi(x) = q for x < 0 and 1 - q otherwise, so x Phi(x) = max(x, 0) - |x| q.  12 vector instructions + v_rcp + v_exp instead of 16 + 2 for
+// 0.5 x (1 + erf(x / sqrt 2)) (no copysign, no 1 + erf), and no cancellation in the negative tail (max |err| 3.3e-7, relative 1.7e-3 at x = -5
+// against 4.6e-7 / 6.8e-2 of that form).  (The GELU of a GEGLU epilogue is vector
+// work beside the tile's MFMAs: profiles/r04_attention_step_mix.txt.)
+__device__ __forceinline__ float gelu_erf_f(float x) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * __expf(-ax * ax);
-    return copysignf(r, x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.23164188f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);
+    const float q = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+    return __builtin_fmaf(-ax, q * e, fmaxf(x, 0.f));
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
 // permuted token index -> stored row: frames of `hw` tokens, `w` wide, walked in 4x8-pixel patches (w == 0: identity).  Patches are
 // numbered in 2x2 QUADS (8x16 pixels, quads row-major, patches row-major inside a quad) when the frame has an even number of patch rows and
