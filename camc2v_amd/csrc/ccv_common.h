@@ -104,7 +104,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const ccv_h2p_t v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
 #else
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    // the vector form here too: ONE v_cvt_pk_bf16_f32 dst, lo, hi wherever the call sits (the scalar form is matched to it in straight-line code
+    // only; behind the runtime branches of the GEMM epilogues it became two converts + a shift + an or)
+    typedef __attribute__((ext_vector_type(2))) __bf16 ccv_b2p_t;
+    const ccv_b2p_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 #endif
 }
 // eight floats -> one MFMA operand fragment

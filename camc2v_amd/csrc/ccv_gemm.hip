@@ -44,15 +44,19 @@ __device__ __forceinline__ uint32_t pack_out2(const CcvGemm& p, float lo, float 
     return p.out_f32 == 2 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
 }
 
-__device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, float o[4], bool add_residual = true) {
+// bias_pre / bias2_pre: the fragment's bias values already in registers (tile epilogues fetch a row fragment's NT column groups together, ahead
+// of the arithmetic: fetched here, every fragment pays a global load + s_waitcnt vmcnt(0) of its own -- 20 dependent round trips per wave and
+// tile -- and, for bias2, a 25-instruction integer division).  Same values, same order of operations: bit-identical results.
+__device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, float o[4], bool add_residual = true, const float4* bias_pre = nullptr,
+                                              const float4* bias2_pre = nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] *= p.alpha;
     if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 bv = bias_pre ? *bias_pre : *reinterpret_cast<const float4*>(p.bias + n);
         o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
     }
     if (p.bias2) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + (long)(m / p.rows_per_batch) * p.ldb2 + n);
+        const float4 bv = bias2_pre ? *bias2_pre : *reinterpret_cast<const float4*>(p.bias2 + (long)(m / p.rows_per_batch) * p.ldb2 + n);
         o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
     }
     if (p.act == 1) {
@@ -77,8 +81,32 @@ __device__ __forceinline__ void epilogue_math(const CcvGemm& p, int m, int n, fl
     }
 }
 
-__device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4]) {
-    epilogue_math(p, m, n, o);
+// the NT column groups (16 apart) of one row of bias values, all loads in flight together; row == nullptr or a group past N: zeros (not used)
+template <int NT>
+__device__ __forceinline__ void preload_cols(const float* row, int n_first, int N, float4 (&v)[NT]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_first + 16 * j;
+        v[j] = (row != nullptr && n < N) ? *reinterpret_cast<const float4*>(row + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// row of the per-batch bias (bias2) that output row m takes, or nullptr
+__device__ __forceinline__ const float* bias2_row(const CcvGemm& p, int m) {
+    return (p.bias2 && m < p.M) ? p.bias2 + (long)(m / p.rows_per_batch) * p.ldb2 : nullptr;
+}
+// The 320-column tiles (NT = 10: 160 accumulator registers) keep the per-fragment fetch of bias2: 40 more live registers spill there.
+template <int NT>
+struct Bias2Pre {
+    static constexpr bool on = NT <= 5;
+    float4 v[on ? NT : 1];
+    __device__ __forceinline__ void load(const CcvGemm& p, int m, int n_first) {
+        if constexpr (on) preload_cols<NT>(bias2_row(p, m), n_first, p.N, v);
+    }
+    __device__ __forceinline__ const float4* at(int j) const { return on ? &v[on ? j : 0] : nullptr; }
+};
+
+__device__ __forceinline__ void epilogue_store(const CcvGemm& p, int m, int n, float o[4], const float4* bias_pre = nullptr, const float4* bias2_pre = nullptr) {
+    epilogue_math(p, m, n, o, true, bias_pre, bias2_pre);
     if (p.out_f32 == 1) {
         *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
@@ -108,28 +136,37 @@ __device__ __forceinline__ bool wide_bf16_ok(const CcvGemm& p) {
     return p.out_f32 != 1 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && g_wide_store != 0;
 }
 
-__device__ __forceinline__ void epilogue_store_pair(const CcvGemm& p, int m, int n, float o0[4], float o1[4]) {
-    epilogue_math(p, m, n, o0);
-    epilogue_math(p, m, n + 16, o1);
+__device__ __forceinline__ void epilogue_store_pair(const CcvGemm& p, int m, int n, float o0[4], float o1[4], const float4* bias_pre = nullptr,
+                                                    const float4* bias2_pre = nullptr) {      // the pre-loaded values of BOTH fragments: [0], [1]
+    epilogue_math(p, m, n, o0, true, bias_pre, bias2_pre);
+    epilogue_math(p, m, n + 16, o1, true, bias_pre ? bias_pre + 1 : nullptr, bias2_pre ? bias2_pre + 1 : nullptr);
     store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, make_uint2(pack_out2(p, o0[0], o0[1]), pack_out2(p, o0[2], o0[3])),
                     make_uint2(pack_out2(p, o1[0], o1[1]), pack_out2(p, o1[2], o1[3])));
 }
 
 // GEGLU: value columns n..n+3 and gate columns n+16..n+19 of the interleaved weight layout
-__device__ __forceinline__ uint2 geglu_value(const CcvGemm& p, int n, const float a_[4], const float g_[4]) {
+// bias_pre: the value fragment's and (bias_pre[1]) the gate fragment's bias values, already in registers (see epilogue_math)
+__device__ __forceinline__ uint2 geglu_value(const CcvGemm& p, int n, const float a_[4], const float g_[4], const float4* bias_pre = nullptr) {
     float o[4];
+    float ba[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const float4 va = bias_pre ? bias_pre[0] : *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 vg = bias_pre ? bias_pre[1] : *reinterpret_cast<const float4*>(p.bias + n + 16);
+        ba[0] = va.x; ba[1] = va.y; ba[2] = va.z; ba[3] = va.w;
+        bg[0] = vg.x; bg[1] = vg.y; bg[2] = vg.z; bg[3] = vg.w;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float a = a_[r] * p.alpha, g = g_[r] * p.alpha;
-        if (p.bias) { a += p.bias[n + r]; g += p.bias[n + 16 + r]; }
+        if (p.bias) { a += ba[r]; g += bg[r]; }
         o[r] = a * gelu_erf_f(g);
     }
     return make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
 }
 
-__device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, const float a_[4], const float g_[4]) {
+__device__ __forceinline__ void epilogue_geglu(const CcvGemm& p, int m, int n, const float a_[4], const float g_[4], const float4* bias_pre = nullptr) {
     const int nc = (n >> 5) * 16 + (n & 15);
-    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = geglu_value(p, n, a_, g_);
+    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + (long)m * p.ldc + nc) = geglu_value(p, n, a_, g_, bias_pre);
 }
 
 
@@ -162,15 +199,20 @@ __device__ __forceinline__ void tile_epilogue_rows(const CcvGemm& p, const f32x4
         }
         __syncthreads();
     }
+    const int n_first = n0 + wn * 16 * NT + 4 * fg;
+    float4 bpre[NT];
+    preload_cols<NT>(p.bias, n_first, p.N, bpre);
     static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const int rl = wm * 16 * MT + 16 * i + fr, m = m0 + rl;
+        Bias2Pre<NT> b2pre;
+        b2pre.load(p, m, n_first);
         static_for<0, NT, 1>([&](auto J) __attribute__((always_inline)) {
             constexpr int j = decltype(J)::value;
             const int cl = wn * 16 * NT + 16 * j + 4 * fg, n = n0 + cl;
             if (m < p.M && n < p.N) {
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue_math(p, m, n, o, false);
+                epilogue_math(p, m, n, o, false, &bpre[j], b2pre.at(j));
                 uint2* slot = reinterpret_cast<uint2*>(smem + rl * PITCH + cl * 2);
                 if (rmw) {
                     const uint2 rv = *slot;
@@ -251,20 +293,25 @@ __device__ __forceinline__ void tile_epilogue_gn(const CcvGemm& p, const f32x4 (
 #pragma unroll
     for (int j = 0; j < NT; ++j) gs[j][0] = gs[j][1] = gs[j][2] = gs[j][3] = 0.f;
     const bool wide = wide_bf16_ok(p);
+    const int n_first = n0 + wn * 16 * NT + 4 * fg;
+    float4 bpre[NT];
+    preload_cols<NT>(p.bias, n_first, p.N, bpre);
     static_for<0, MT, 1>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const int m = m0 + wm * 16 * MT + 16 * i + fr;      // every row is inside M (host check)
+        Bias2Pre<NT> b2pre;
+        b2pre.load(p, m, n_first);
         static_for<0, NT, 2>([&](auto J) __attribute__((always_inline)) {      // fragments two at a time: one 16-byte store per lane
             constexpr int j = decltype(J)::value;                              // (store_pair_bf16) where both are in range
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
             if (n < p.N) {                                   // columns past N are not stored and add nothing
                 float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epilogue_math(p, m, n, o);
+                epilogue_math(p, m, n, o, true, &bpre[j], b2pre.at(j));
                 bool paired = false;
                 if constexpr (j + 1 < NT) {
                     if (wide && n - 4 * fg + 32 <= p.N) {
                         float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                        epilogue_math(p, m, n + 16, o1);
+                        epilogue_math(p, m, n + 16, o1, true, &bpre[j + 1], b2pre.at(j + 1));
                         const uint2 a = round_pack(p, o), b = round_pack(p, o1);
                         store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, n, a, b);
                         gs[j + 1][0] += o1[0] + o1[1]; gs[j + 1][1] += o1[0] * o1[0] + o1[1] * o1[1];
@@ -278,7 +325,7 @@ __device__ __forceinline__ void tile_epilogue_gn(const CcvGemm& p, const f32x4 (
                 if constexpr (j + 1 < NT) {
                     if (!paired && n + 16 < p.N) {
                         float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
-                        epilogue_math(p, m, n + 16, o1);
+                        epilogue_math(p, m, n + 16, o1, true, &bpre[j + 1], b2pre.at(j + 1));
                         store_rounded(p, m, n + 16, o1);
                         gs[j + 1][0] += o1[0] + o1[1]; gs[j + 1][1] += o1[0] * o1[0] + o1[1] * o1[1];
                         gs[j + 1][2] += o1[2] + o1[3]; gs[j + 1][3] += o1[2] * o1[2] + o1[3] * o1[3];
@@ -831,6 +878,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
             return;
         }
         if (NT % 2 == 0 && p.geglu) {
+            float4 gpre[NT];                  // bias of the row's value / gate fragments, fetched together
+            preload_cols<NT>(p.bias, n0 + wn * 16 * NT + 4 * fg, p.N, gpre);
             static_for<0, NT, 4>([&](auto J) __attribute__((always_inline)) {   // (value, gate) fragment pairs, two pairs at a time
                 constexpr int j = decltype(J)::value;
                 if constexpr (j + 1 < NT) {
@@ -843,19 +892,23 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
                             const float g2[4] = {acc[i][j + 3][0], acc[i][j + 3][1], acc[i][j + 3][2], acc[i][j + 3][3]};
                             if (wide && n - 4 * fg + 64 <= p.N) {   // both output groups in range: one 16-byte store per lane
                                 store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, (n >> 5) * 16 + (n & 15),
-                                                geglu_value(p, n, a_, g_), geglu_value(p, n + 32, a2, g2));
+                                                geglu_value(p, n, a_, g_, &gpre[j]), geglu_value(p, n + 32, a2, g2, &gpre[j + 2]));
                             } else {
-                                epilogue_geglu(p, m, n, a_, g_);
-                                if (n + 32 < p.N) epilogue_geglu(p, m, n + 32, a2, g2);
+                                epilogue_geglu(p, m, n, a_, g_, &gpre[j]);
+                                if (n + 32 < p.N) epilogue_geglu(p, m, n + 32, a2, g2, &gpre[j + 2]);
                             }
                         } else {
-                            epilogue_geglu(p, m, n, a_, g_);
+                            epilogue_geglu(p, m, n, a_, g_, &gpre[j]);
                         }
                     }
                 }
             });
             return;
         }
+        float4 bpre[NT];                  // this row's bias fragments, fetched together (epilogue_math)
+        Bias2Pre<NT> b2pre;
+        preload_cols<NT>(p.bias, n0 + wn * 16 * NT + 4 * fg, p.N, bpre);
+        b2pre.load(p, m, n0 + wn * 16 * NT + 4 * fg);
         static_for<0, NT, 2>([&](auto J) __attribute__((always_inline)) {   // fragments two at a time
             constexpr int j = decltype(J)::value;
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
@@ -864,13 +917,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const CcvGemm p) {   // 1
                 if constexpr (j + 1 < NT) {
                     float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
                     if (wide && n - 4 * fg + 32 <= p.N) {   // bf16 out, both fragments in range: one 16-byte store per lane
-                        epilogue_store_pair(p, m, n, o, o1);
+                        epilogue_store_pair(p, m, n, o, o1, &bpre[j], b2pre.at(j));
                     } else {
-                        epilogue_store(p, m, n, o);
-                        if (n + 16 < p.N) epilogue_store(p, m, n + 16, o1);
+                        epilogue_store(p, m, n, o, &bpre[j], b2pre.at(j));
+                        if (n + 16 < p.N) epilogue_store(p, m, n + 16, o1, &bpre[j + 1], b2pre.at(j + 1));
                     }
                 } else {
-                    epilogue_store(p, m, n, o);
+                    epilogue_store(p, m, n, o, &bpre[j], b2pre.at(j));
                 }
             }
         });
@@ -1065,6 +1118,8 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             return;
         }
         if (NT % 2 == 0 && p.geglu) {   // N is a multiple of the tile width here: every fragment is in range
+            float4 gpre[NT];                  // bias of the row's value / gate fragments, fetched together
+            preload_cols<NT>(p.bias, n0 + wn * 16 * NT + 4 * fg, p.N, gpre);
             static_for<0, NT, 4>([&](auto J) __attribute__((always_inline)) {   // (value, gate) fragment pairs, two pairs at a time
                 constexpr int j = decltype(J)::value;
                 if constexpr (j + 1 < NT) {
@@ -1076,18 +1131,22 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
                         const float g2[4] = {acc[i][j + 3][0], acc[i][j + 3][1], acc[i][j + 3][2], acc[i][j + 3][3]};
                         if (wide) {
                             store_pair_bf16(static_cast<uint16_t*>(p.C) + (long)m * p.ldc, (n >> 5) * 16 + (n & 15),
-                                            geglu_value(p, n, a_, g_), geglu_value(p, n + 32, a2, g2));
+                                            geglu_value(p, n, a_, g_, &gpre[j]), geglu_value(p, n + 32, a2, g2, &gpre[j + 2]));
                         } else {
-                            epilogue_geglu(p, m, n, a_, g_);
-                            epilogue_geglu(p, m, n + 32, a2, g2);
+                            epilogue_geglu(p, m, n, a_, g_, &gpre[j]);
+                            epilogue_geglu(p, m, n + 32, a2, g2, &gpre[j + 2]);
                         }
                     } else {
-                        epilogue_geglu(p, m, n, a_, g_);
+                        epilogue_geglu(p, m, n, a_, g_, &gpre[j]);
                     }
                 }
             });
             return;
         }
+        float4 bpre[NT];                  // this row's bias fragments, fetched together (epilogue_math)
+        Bias2Pre<NT> b2pre;
+        preload_cols<NT>(p.bias, n0 + wn * 16 * NT + 4 * fg, p.N, bpre);
+        b2pre.load(p, m, n0 + wn * 16 * NT + 4 * fg);
         static_for<0, NT, 2>([&](auto J) __attribute__((always_inline)) {   // fragments two at a time
             constexpr int j = decltype(J)::value;
             const int n = n0 + wn * 16 * NT + 16 * j + 4 * fg;
@@ -1095,13 +1154,13 @@ __global__ __launch_bounds__(256, (ST == 2 ? (MT * NT <= 20 ? 3 : 2) : 1)) void 
             if constexpr (j + 1 < NT) {
                 float o1[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
                 if (wide) {
-                    epilogue_store_pair(p, m, n, o, o1);
+                    epilogue_store_pair(p, m, n, o, o1, &bpre[j], b2pre.at(j));
                 } else {
-                    epilogue_store(p, m, n, o);
-                    epilogue_store(p, m, n + 16, o1);
+                    epilogue_store(p, m, n, o, &bpre[j], b2pre.at(j));
+                    epilogue_store(p, m, n + 16, o1, &bpre[j + 1], b2pre.at(j + 1));
                 }
             } else {
-                epilogue_store(p, m, n, o);
+                epilogue_store(p, m, n, o, &bpre[j], b2pre.at(j));
             }
         });
     });
