@@ -502,7 +502,9 @@ def result_line(elapsed, steps, warmup, world, use_graph, dev_ms=None, dom=None,
                     flops_per_launch=dom["flops_per_launch"], executed_fraction=dom["executed_fraction"], problem=dom["problem"],
                     visited_block_fraction=dom["visited_block_fraction"],
                     us_per_launch_isolated=dom.get("us_per_launch_isolated"), launches_timed_in_model=dom.get("launches_timed_in_model"))
-    if os.path.exists(TRAFFIC_FILE):     # HBM-side bytes per launch of the dominant kernel from this round's PMC passes
+    # HBM-side bytes per launch of the dominant kernel from this round's PMC passes -- collected on the metric's configuration (c1) and for the
+    # masked attention kernel: the other configurations report null (no counter run of theirs is committed)
+    if os.path.exists(TRAFFIC_FILE) and WORKLOAD_KEY == "c1" and dom is not None:
         try:
             tr = json.load(open(TRAFFIC_FILE))
             roof["traffic"] = tr.get("dominant_kernel_bytes_per_launch")
