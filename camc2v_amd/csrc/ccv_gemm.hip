@@ -189,13 +189,24 @@ __device__ __forceinline__ void tile_epilogue_rows(const CcvGemm& p, const f32x4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, fr = lane & 15, fg = lane >> 4;
     const bool rmw = p.residual != nullptr;
     __syncthreads();      // every wave is past its last fragment read of the operand stages
+    // the tile's 16-byte chunks are dealt to the 256 threads IT at a time, fully unrolled with every load issued before the first use: as a
+    // rolled loop each iteration waited for its own load (s_waitcnt vmcnt(0) + ds_write per chunk: IT dependent L2 round trips per tile)
+    constexpr int CHUNKS = BM * CPR, IT = (CHUNKS + 255) / 256;
     if (rmw) {
         const uint16_t* R = static_cast<const uint16_t*>(p.residual);
-        for (int c = tid; c < BM * CPR; c += 256) {
+        uint4 rv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = tid + 256 * it;
             const int row = c / CPR, col = 8 * (c - row * CPR), m = m0 + row, n = n0 + col;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (m < p.M && n < p.N) v = *reinterpret_cast<const uint4*>(R + (long)m * p.ldr + n);
-            *reinterpret_cast<uint4*>(smem + row * PITCH + col * 2) = v;
+            rv[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < CHUNKS && m < p.M && n < p.N) rv[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.ldr + n);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c / CPR, col = 8 * (c - row * CPR);
+            if (c < CHUNKS) *reinterpret_cast<uint4*>(smem + row * PITCH + col * 2) = rv[it];
         }
         __syncthreads();
     }
@@ -225,9 +236,19 @@ __device__ __forceinline__ void tile_epilogue_rows(const CcvGemm& p, const f32x4
     });
     __syncthreads();
     uint16_t* Cp = static_cast<uint16_t*>(p.C);
-    for (int c = tid; c < BM * CPR; c += 256) {
+    uint4 ov[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = tid + 256 * it;
+        const int row = c / CPR, col = 8 * (c - row * CPR);
+        ov[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (c < CHUNKS) ov[it] = *reinterpret_cast<const uint4*>(smem + row * PITCH + col * 2);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = tid + 256 * it;
         const int row = c / CPR, col = 8 * (c - row * CPR), m = m0 + row, n = n0 + col;
-        if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(Cp + (long)m * p.ldc + n) = *reinterpret_cast<const uint4*>(smem + row * PITCH + col * 2);
+        if (c < CHUNKS && m < p.M && n < p.N) *reinterpret_cast<uint4*>(Cp + (long)m * p.ldc + n) = ov[it];
     }
 }
 
