@@ -1195,21 +1195,46 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const CcvGemm p) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4), n = (int)(i % n4) * 4;
         if (p.geglu && (n & 16)) continue;  // gate columns are consumed together with their value columns
+        // the partial slabs four at a time with their loads in flight together (rolled, every slab waited for its own load: split_k dependent L2
+        // round trips per thread), added in slab order as before; the bias values are requested ahead of the sums
         auto sum = [&](int col, float o[4]) {
             o[0] = o[1] = o[2] = o[3] = 0.f;
-            for (int sp = 0; sp < p.split_k; ++sp) {
-                const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(p.ws) + ((long)sp * p.M + m) * p.N + col);
+            const float* src = static_cast<const float*>(p.ws) + (long)m * p.N + col;
+            const long slab = (long)p.M * p.N;
+            int sp = 0;
+            for (; sp + 4 <= p.split_k; sp += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + sp * slab), v1 = *reinterpret_cast<const float4*>(src + (sp + 1) * slab);
+                const float4 v2 = *reinterpret_cast<const float4*>(src + (sp + 2) * slab), v3 = *reinterpret_cast<const float4*>(src + (sp + 3) * slab);
+                o[0] += v0.x; o[1] += v0.y; o[2] += v0.z; o[3] += v0.w;
+                o[0] += v1.x; o[1] += v1.y; o[2] += v1.z; o[3] += v1.w;
+                o[0] += v2.x; o[1] += v2.y; o[2] += v2.z; o[3] += v2.w;
+                o[0] += v3.x; o[1] += v3.y; o[2] += v3.z; o[3] += v3.w;
+            }
+            if (sp + 2 <= p.split_k) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + sp * slab), v1 = *reinterpret_cast<const float4*>(src + (sp + 1) * slab);
+                o[0] += v0.x; o[1] += v0.y; o[2] += v0.z; o[3] += v0.w;
+                o[0] += v1.x; o[1] += v1.y; o[2] += v1.z; o[3] += v1.w;
+                sp += 2;
+            }
+            if (sp < p.split_k) {
+                const float4 v = *reinterpret_cast<const float4*>(src + sp * slab);
                 o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
             }
         };
         float o[4];
-        sum(n, o);
         if (p.geglu) {
+            float4 gpre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            if (p.bias) { gpre[0] = *reinterpret_cast<const float4*>(p.bias + n); gpre[1] = *reinterpret_cast<const float4*>(p.bias + n + 16); }
             float g[4];
+            sum(n, o);
             sum(n + 16, g);
-            epilogue_geglu(p, m, n, o, g);
+            epilogue_geglu(p, m, n, o, g, gpre);
         } else {
-            epilogue_store(p, m, n, o);
+            float4 bpre[1], b2pre[1];
+            preload_cols<1>(p.bias, n, p.N, bpre);
+            preload_cols<1>(bias2_row(p, m), n, p.N, b2pre);
+            sum(n, o);
+            epilogue_store(p, m, n, o, bpre, b2pre);
         }
     }
 }
@@ -1227,12 +1252,33 @@ __global__ __launch_bounds__(1024) void gemm_splitk_reduce_gn(const CcvGemm p, i
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int m = r0 + roff; m < r0 + RB; m += R) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int sp = 0; sp < p.split_k; ++sp) {
-            const float4 v = *reinterpret_cast<const float4*>(ws + ((long)sp * p.M + m) * p.N + n);
-            o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+        float4 bpre[1], b2pre[1];                 // bias values requested ahead of the sums (see gemm_splitk_reduce)
+        preload_cols<1>(p.bias, n, p.N, bpre);
+        preload_cols<1>(bias2_row(p, m), n, p.N, b2pre);
+        {
+            const float* src = ws + (long)m * p.N + n;
+            const long slab = (long)p.M * p.N;
+            int sp = 0;
+            for (; sp + 4 <= p.split_k; sp += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + sp * slab), v1 = *reinterpret_cast<const float4*>(src + (sp + 1) * slab);
+                const float4 v2 = *reinterpret_cast<const float4*>(src + (sp + 2) * slab), v3 = *reinterpret_cast<const float4*>(src + (sp + 3) * slab);
+                o[0] += v0.x; o[1] += v0.y; o[2] += v0.z; o[3] += v0.w;
+                o[0] += v1.x; o[1] += v1.y; o[2] += v1.z; o[3] += v1.w;
+                o[0] += v2.x; o[1] += v2.y; o[2] += v2.z; o[3] += v2.w;
+                o[0] += v3.x; o[1] += v3.y; o[2] += v3.z; o[3] += v3.w;
+            }
+            if (sp + 2 <= p.split_k) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + sp * slab), v1 = *reinterpret_cast<const float4*>(src + (sp + 1) * slab);
+                o[0] += v0.x; o[1] += v0.y; o[2] += v0.z; o[3] += v0.w;
+                o[0] += v1.x; o[1] += v1.y; o[2] += v1.z; o[3] += v1.w;
+                sp += 2;
+            }
+            if (sp < p.split_k) {
+                const float4 v = *reinterpret_cast<const float4*>(src + sp * slab);
+                o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+            }
         }
-        epilogue_math(p, m, n, o);
+        epilogue_math(p, m, n, o, true, bpre, b2pre);
         store_rounded(p, m, n, o);
         a0 += o[0] + o[1]; a1 += o[0] * o[0] + o[1] * o[1];
         a2 += o[2] + o[3]; a3 += o[2] * o[2] + o[3] * o[3];
