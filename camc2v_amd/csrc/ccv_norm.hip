@@ -467,10 +467,15 @@ inline int gn_threads8(int C) {
     int r = (256 + cols - 1) / cols;   // at least 256 threads (the statistics prologue uses 256)
     return cols * (r < 1 ? 1 : r);
 }
+inline bool gn_aligned16(const void* x, const void* y) {      // gn_apply8 moves 16 bytes per lane: x and y on 16-byte boundaries (rows are: C % 8 == 0)
+    return ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+}
+#define GN_FIRST2_(a, b, ...) a, b
+#define GN_FIRST2(...) GN_FIRST2_(__VA_ARGS__)
 #define GN_APPLY(kind, grid, st, C, ...)                                                                                   \
     do {                                                                                                                   \
         static const bool wide_ = [] { const char* e = getenv("CCV_GN_APPLY8"); return !(e && e[0] == '0'); }();           \
-        if ((kind) != CCV_F32 && wide_ && (C) % 8 == 0 && gn_threads8(C) <= 1024) {                                        \
+        if ((kind) != CCV_F32 && wide_ && (C) % 8 == 0 && gn_threads8(C) <= 1024 && gn_aligned16(GN_FIRST2(__VA_ARGS__))) {    \
             if ((kind) == CCV_F16) hipLaunchKernelGGL(gn_apply8<CCV_F16>, grid, dim3(gn_threads8(C)), 0, st, __VA_ARGS__); \
             else hipLaunchKernelGGL(gn_apply8<CCV_BF16>, grid, dim3(gn_threads8(C)), 0, st, __VA_ARGS__);                  \
         } else {                                                                                                           \

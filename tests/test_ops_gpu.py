@@ -1067,6 +1067,26 @@ def test_groupnorm_fp16_rows(ops, rows, C, instances):
     assert_close(y, ops.groupnorm(x.float(), gamma, beta, instances=instances, eps=1e-5, silu=True), 8e-3, "fp16 rows vs the same values as fp32 rows")
 
 
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+def test_groupnorm_rows_off_a_16_byte_boundary(ops, kind):
+    """The two-byte GroupNorm apply moves 16 bytes per lane (gn_apply8); rows that start 8 bytes off a 16-byte boundary (a view into a
+    larger buffer) must take the 8-byte kernel and give the very same bits."""
+    rows, C, inst = 4096, 320, 4          # chunked two-launch path
+    gamma, beta = rnd(C, seed=44, dtype=torch.float32), rnd(C, seed=45, dtype=torch.float32)
+    vals = rnd(rows, C, seed=43, dtype=torch.float32) * 1.5 + 0.2
+    x = _f16(vals) if kind == "f16" else vals.to(ops.BF16)
+    buf = torch.empty(rows * C + 8, dtype=x.dtype, device=x.device)
+    off = buf[4:4 + rows * C].view(rows, C)      # 8 bytes past the allocation's (256-byte aligned) start
+    off.copy_(x)
+    assert off.data_ptr() % 16 == 8 and x.data_ptr() % 16 == 0
+    y = ops.groupnorm(x, gamma, beta, instances=inst, eps=1e-5, silu=True)
+    y_off = ops.groupnorm(off, gamma, beta, instances=inst, eps=1e-5, silu=True)
+    assert torch.equal(y, y_off)
+    xr = x.float().reshape(inst, rows // inst, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xr, 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(rows, C)
+    assert_close(y, ref, 1e-2, "groupnorm, 16-byte apply")
+
+
 @pytest.mark.parametrize("rows,C", [(32768, 320), (8192, 640), (2048, 1280), (100, 320)])
 def test_layernorm_fp16_rows(ops, rows, C):
     x = _f16(rnd(rows, C, seed=35, dtype=torch.float32) * 2.0 - 0.5)
